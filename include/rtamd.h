@@ -1,0 +1,208 @@
+/*
+ * rtamd.h — C-ABI drop-in boundary for the ray-tracing hot path on MI355X (gfx950).
+ *
+ * This header is everything the reference's host would bind (bindgen / cc in
+ * build.rs) to replace its OpenGL full-screen-pass dispatch of
+ * res/shaders/ray_trace_and_shade.frag (and of the split-pipeline sibling
+ * res/shaders/ray_trace/ray_trace.frag) by hand-written HIP kernels.  Plain
+ * pointers and sizes only; no C++ or torch types.  All citations are relative
+ * to the reference tree.
+ *
+ * Conventions
+ *   - every function returns an rtamd_status (0 = ok, negative = error) and never
+ *     unwinds across the boundary; rtamd_last_error() gives the text (the
+ *     reference maps errors to Result<_, enum>, src/util/error.rs:4-59);
+ *   - inputs are borrowed for the duration of the call and copied to HBM, as
+ *     glBufferData does at src/gl_wrapper/buffer.rs:9-19; outputs go into
+ *     caller-provided buffers;
+ *   - a context is owned by one caller thread at a time (the reference's GL
+ *     context is single-threaded too), one context per GPU / per process rank;
+ *   - "host" entry points take host pointers and are synchronous; "_device"
+ *     entry points take device pointers (HBM-resident inputs/outputs), enqueue on
+ *     the context's stream and return without waiting;
+ *   - pixel i of a frame uses ray i and produces output i: the library never
+ *     flips rows.  With on-device ray generation row 0 is the BOTTOM row (GL
+ *     window convention, util/quad-11.vert:8).
+ *   - the library has no CPU fallback: without a usable GPU every compute entry
+ *     point fails with RTAMD_ERR_DEVICE.
+ */
+#ifndef RTAMD_H
+#define RTAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rtamd_status {
+    RTAMD_OK = 0,
+    RTAMD_ERR_INVALID_ARGUMENT = -1, /* NULL / zero-sized / inconsistent argument */
+    RTAMD_ERR_EMPTY_SCENE = -2,      /* the reference panics on &data[0] of an empty Vec (buffer.rs:15) */
+    RTAMD_ERR_NO_SCENE = -3,         /* render/trace before rtamd_upload_scene */
+    RTAMD_ERR_MALFORMED_SCENE = -4,  /* node / triangle / vertex index out of range, cyclic or too deep tree */
+    RTAMD_ERR_DEVICE = -5,           /* HIP runtime error or no GPU */
+    RTAMD_ERR_OUT_OF_MEMORY = -6
+} rtamd_status;
+
+typedef struct rtamd_context rtamd_context;
+
+/* Value written to hit_id outputs for pixels whose primary ray misses
+ * (the fused shader leaves triangleIdx at its initial 0 and shades the sky,
+ * ray_trace_and_shade.frag:201,232-234). */
+#define RTAMD_NO_HIT 0xFFFFFFFFu
+
+/* Framebuffer tile used to shard a frame over ranks (interleaved tiles, scene
+ * replicated): tile k (row-major over ceil(W/32) x ceil(H/32)) belongs to rank
+ * k % tile_world. */
+#define RTAMD_TILE_DIM 32u
+
+/* ---- context ---------------------------------------------------------- */
+
+/* Replaces GL context + program creation (src/main.rs:23,33-50). */
+int rtamd_context_create(int device_ordinal, rtamd_context **out_ctx);
+void rtamd_context_destroy(rtamd_context *ctx);
+
+/* Text of the last error on this context (ctx == NULL: last error of a failed
+ * rtamd_context_create on this thread).  Never NULL. */
+const char *rtamd_last_error(const rtamd_context *ctx);
+
+/* Use an existing hipStream_t (passed as void*) for all "_device" work of this
+ * context; NULL restores the context's own stream. */
+int rtamd_context_set_stream(rtamd_context *ctx, void *hip_stream);
+
+/* Block until all work enqueued by this context has finished. */
+int rtamd_synchronize(rtamd_context *ctx);
+
+/* ---- scene upload ------------------------------------------------------ */
+
+/* Exactly the five slices the reference uploads as SSBOs at src/main.rs:93-102
+ * (bindings 0..4 of ray_trace_and_shade.frag:47-51):
+ *   nodes      BVH::data()            src/raytracing/bvh.rs:49-51     36-byte records
+ *                                     (6 x f32 bounds, u32 is_leaf, u32 a, u32 b; types.rs:101-109)
+ *   triangles  Model::triangles()     src/rendering/model.rs:20       16-byte records (p0,p1,p2,mat_idx), leaf order
+ *   positions  Model::positions()     model.rs:22                     3 x f32 per vertex
+ *   tex_coords Model::tex_coords()    model.rs:23   optional (NULL)   2 x f32 per vertex
+ *   normals    Model::normals()       model.rs:24   optional (NULL)   3 x f32 per vertex
+ */
+typedef struct rtamd_scene_desc {
+    const void *nodes;
+    uint32_t node_count;
+    const void *triangles;
+    uint32_t triangle_count;
+    const float *positions;
+    uint32_t vertex_count;
+    const float *tex_coords;
+    const float *normals;
+} rtamd_scene_desc;
+
+/* Copies the scene to HBM and builds the device layout (64-byte two-child node
+ * records, 48-byte precomputed-edge triangle records).  Validates every index.
+ * Replaces ShaderStorageBuffer::new + buffer_data (src/gl_wrapper/buffer.rs:84-108). */
+int rtamd_upload_scene(rtamd_context *ctx, const rtamd_scene_desc *scene);
+
+/* Albedo texture for material slot 0 or 1 (modelTextures[2],
+ * ray_trace_and_shade.frag:21): tightly packed RGB8 rows, first row first, as
+ * Texture::from_data hands them to glTexImage2D (src/gl_wrapper/texture.rs:11-26,
+ * 65-79).  Sampling is LINEAR min/mag, REPEAT wrap, no mip maps, RGBA8 unorm.
+ * A slot never uploaded samples as opaque white. */
+int rtamd_upload_texture(rtamd_context *ctx, uint32_t slot, const uint8_t *rgb8, uint32_t width, uint32_t height);
+
+/* ---- fused render: ray_trace_and_shade.frag:main (:195-235) --------------- */
+
+typedef struct rtamd_frame_desc {
+    uint32_t width, height;
+    /* Per-pixel rays: the `dir` / `org` RGB32F textures (uniform locations 0, 1;
+     * :17-18,196-197), 3 floats per pixel.  If dir is NULL the rays are generated
+     * on the device from the camera fields below (ray_create.frag:12). */
+    const float *dir;
+    const float *org;
+    /* Camera for on-device ray generation: inverse(proj*view), column-major
+     * (src/main.rs:149), near/far (camera.rs:6-7) and the eye position, which is
+     * the origin of every primary ray. */
+    float inv_proj_view[16];
+    float near_plane, far_plane;
+    float cam_pos[3];
+    /* Uniform bools at locations 2 / 3 (:19-20). */
+    uint32_t has_tex_coords;
+    uint32_t has_normals;
+    /* Interleaved-tile shard of the frame this call renders (tile_world >= 1,
+     * tile_rank < tile_world).  tile_world == 1 renders the whole frame. */
+    uint32_t tile_rank, tile_world;
+} rtamd_frame_desc;
+
+/* Output buffers; any pointer may be NULL (that output is skipped).
+ * Layout when desc.tile_world == 1: scan-line order, index = y*width + x.
+ * Layout when desc.tile_world  > 1: compact tile-major — local tile j (global
+ * tile j*tile_world + tile_rank) occupies pixels [j*1024, (j+1)*1024), row-major
+ * 32x32 inside the tile; see rtamd_tiles_per_rank / rtamd_assemble_tiles_device. */
+typedef struct rtamd_frame_out {
+    float *rgba32f;    /* fragCol (:231,233), 4 floats per pixel, unclamped */
+    uint32_t *hit_id;  /* closest-hit triangle index (leaf order) or RTAMD_NO_HIT */
+    float *hit_t;      /* primary t, or 1e6 (the shader's initial value, :199) on a miss */
+    uint32_t *counts;  /* 2 per pixel: AABB tests, triangle tests (the shader's `intersections`, :115,123,138, split by kind; primary + shadow) */
+} rtamd_frame_out;
+
+/* Host buffers in, host buffers out; synchronous.  Replaces bind + set_uniform_* +
+ * quad_geometry.draw() + read-back (src/main.rs:204-230 pattern; shader.rs:128-174;
+ * geometry_set.rs:34-44). */
+int rtamd_render(rtamd_context *ctx, const rtamd_frame_desc *desc, const rtamd_frame_out *out);
+
+/* Same, with desc->dir / desc->org and every pointer in `out` being DEVICE
+ * pointers; enqueues on the context's stream and returns. */
+int rtamd_render_device(rtamd_context *ctx, const rtamd_frame_desc *desc, const rtamd_frame_out *out);
+
+/* ---- split-pipeline trace: ray_trace/ray_trace.frag:main (:131-143) -------- */
+
+/* n rays in, n hit records out: hits[4*i..] = (t, u, v, uintBitsToFloat(triangle index)).
+ * t starts at MISS = 1e30 (:136); a ray with dir == (0,0,0) is "no ray" (:133) and
+ * yields the clear value (1e30, 0, 0, 0) that src/main.rs:179 puts in the target. */
+int rtamd_trace(rtamd_context *ctx, uint64_t n, const float *org, const float *dir, float *hits);
+int rtamd_trace_device(rtamd_context *ctx, uint64_t n, const float *org, const float *dir, float *hits);
+
+/* ---- ray generation: ray_trace/ray_create.frag:12 + util/quad-11.vert:8 ---- */
+
+/* dir_out: 3 floats per pixel, scan-line order, row 0 = bottom row. */
+int rtamd_generate_rays(rtamd_context *ctx, uint32_t width, uint32_t height, const float inv_proj_view[16],
+                        float near_plane, float far_plane, float *dir_out);
+int rtamd_generate_rays_device(rtamd_context *ctx, uint32_t width, uint32_t height, const float inv_proj_view[16],
+                               float near_plane, float far_plane, float *dir_out);
+
+/* ---- multi-GPU frame assembly helpers -------------------------------------- */
+
+/* Number of 32x32 tiles a rank owns, maximised over ranks (the per-rank block
+ * size, in tiles, of the gather buffer). */
+uint32_t rtamd_tiles_per_rank(uint32_t width, uint32_t height, uint32_t tile_world);
+
+/* Root side of the RCCL gather: `gathered` holds tile_world rank-major blocks of
+ * rtamd_tiles_per_rank()*1024 pixels, `elems_per_pixel` 4-byte words each (4 for
+ * rgba32f, 1 for hit_id / hit_t); writes the scan-line frame.  Device pointers. */
+int rtamd_assemble_tiles_device(rtamd_context *ctx, const void *gathered, uint32_t width, uint32_t height,
+                                uint32_t tile_world, uint32_t elems_per_pixel, void *frame_out);
+
+/* ---- introspection ---------------------------------------------------------- */
+
+typedef struct rtamd_scene_info {
+    uint32_t node_count, triangle_count, vertex_count;
+    uint32_t inner_node_count;   /* 64-byte device records */
+    uint32_t big_leaf_count;     /* leaves that need the overflow table */
+    uint32_t max_depth;          /* deepest root-to-leaf path */
+    uint64_t device_bytes;       /* HBM held by the scene */
+} rtamd_scene_info;
+int rtamd_get_scene_info(const rtamd_context *ctx, rtamd_scene_info *info);
+
+/* Milliseconds the main kernel of the last *_device / host call took, measured
+ * with HIP events on the stream it ran on (blocks until that kernel is done). */
+int rtamd_last_kernel_ms(rtamd_context *ctx, float *ms);
+
+/* Kernel variant used by render/trace: 0 = default (persistent wave64 queue),
+ * 1 = one lane per pixel, static 8x8 blocks (A/B baseline). */
+int rtamd_set_kernel_variant(rtamd_context *ctx, int variant);
+
+const char *rtamd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTAMD_H */

@@ -1,0 +1,148 @@
+"""ctypes loaders for the two in-tree shared libraries.
+
+librtamd_host.so  host scene layer (CPU)          include/rtamd_host.h
+librtamd.so       C-ABI device library (gfx950)   include/rtamd.h
+
+Both are built by raytracer_amd/csrc/Makefile (see __graft_entry__.build()).
+There is deliberately no fallback: a missing library raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+HOST_LIB_PATH = os.path.join(LIB_DIR, "librtamd_host.so")
+DEVICE_LIB_PATH = os.path.join(LIB_DIR, "librtamd.so")
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_u8_p = ctypes.POINTER(ctypes.c_uint8)
+c_u32_p = ctypes.POINTER(ctypes.c_uint32)
+
+
+class ModelInfo(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint32) for n in (
+        "triangle_count", "vertex_count", "node_count", "material_count",
+        "has_tex_coords", "has_normals", "has_bvh")]
+
+
+class SceneDesc(ctypes.Structure):
+    _fields_ = [
+        ("nodes", ctypes.c_void_p), ("node_count", ctypes.c_uint32),
+        ("triangles", ctypes.c_void_p), ("triangle_count", ctypes.c_uint32),
+        ("positions", ctypes.c_void_p), ("vertex_count", ctypes.c_uint32),
+        ("tex_coords", ctypes.c_void_p), ("normals", ctypes.c_void_p),
+    ]
+
+
+class FrameDesc(ctypes.Structure):
+    _fields_ = [
+        ("width", ctypes.c_uint32), ("height", ctypes.c_uint32),
+        ("dir", ctypes.c_void_p), ("org", ctypes.c_void_p),
+        ("inv_proj_view", ctypes.c_float * 16),
+        ("near_plane", ctypes.c_float), ("far_plane", ctypes.c_float),
+        ("cam_pos", ctypes.c_float * 3),
+        ("has_tex_coords", ctypes.c_uint32), ("has_normals", ctypes.c_uint32),
+        ("tile_rank", ctypes.c_uint32), ("tile_world", ctypes.c_uint32),
+    ]
+
+
+class FrameOut(ctypes.Structure):
+    _fields_ = [
+        ("rgba32f", ctypes.c_void_p), ("hit_id", ctypes.c_void_p),
+        ("hit_t", ctypes.c_void_p), ("counts", ctypes.c_void_p),
+    ]
+
+
+class SceneInfo(ctypes.Structure):
+    _fields_ = [
+        ("node_count", ctypes.c_uint32), ("triangle_count", ctypes.c_uint32), ("vertex_count", ctypes.c_uint32),
+        ("inner_node_count", ctypes.c_uint32), ("big_leaf_count", ctypes.c_uint32), ("max_depth", ctypes.c_uint32),
+        ("device_bytes", ctypes.c_uint64),
+    ]
+
+
+_host = None
+_device = None
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise RuntimeError(f"{HOST_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               f"or `make -C raytracer_amd/csrc host`")
+        L = ctypes.CDLL(HOST_LIB_PATH)
+        L.rtamd_model_parse_obj.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.c_char_p, ctypes.c_size_t]
+        L.rtamd_model_parse_obj.restype = ctypes.c_int
+        L.rtamd_model_from_arrays.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32,
+                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        L.rtamd_model_from_arrays.restype = ctypes.c_int
+        L.rtamd_model_free.argtypes = [ctypes.c_void_p]
+        L.rtamd_model_free.restype = None
+        L.rtamd_model_build_bvh.argtypes = [ctypes.c_void_p]
+        L.rtamd_model_build_bvh.restype = ctypes.c_int
+        L.rtamd_model_get_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ModelInfo)]
+        L.rtamd_model_get_info.restype = None
+        for name in ("rtamd_model_triangles", "rtamd_model_positions", "rtamd_model_tex_coords",
+                     "rtamd_model_normals", "rtamd_model_bvh_nodes"):
+            getattr(L, name).argtypes = [ctypes.c_void_p]
+            getattr(L, name).restype = ctypes.c_void_p
+        L.rtamd_model_material_name.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+        L.rtamd_model_material_name.restype = ctypes.c_char_p
+        L.rtamd_camera_matrices.argtypes = [ctypes.c_float, ctypes.c_float, c_float_p, c_float_p, c_float_p,
+                                            c_float_p, c_float_p, c_float_p]
+        L.rtamd_camera_matrices.restype = ctypes.c_int
+        L.rtamd_camera_direction.argtypes = [ctypes.c_float, ctypes.c_float, c_float_p]
+        L.rtamd_camera_direction.restype = None
+        L.rtamd_host_generate_primary_rays.argtypes = [c_float_p, ctypes.c_float, ctypes.c_float, ctypes.c_uint32,
+                                                       ctypes.c_uint32, c_float_p]
+        L.rtamd_host_generate_primary_rays.restype = None
+        _host = L
+    return _host
+
+
+def device_lib():
+    global _device
+    if _device is None:
+        if not os.path.exists(DEVICE_LIB_PATH):
+            raise RuntimeError(f"{DEVICE_LIB_PATH} is missing: the HIP library must be built "
+                               f"(`make -C raytracer_amd/csrc device`); there is no CPU fallback")
+        L = ctypes.CDLL(DEVICE_LIB_PATH)
+        vp = ctypes.c_void_p
+        L.rtamd_context_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+        L.rtamd_context_create.restype = ctypes.c_int
+        L.rtamd_context_destroy.argtypes = [vp]
+        L.rtamd_context_destroy.restype = None
+        L.rtamd_last_error.argtypes = [vp]
+        L.rtamd_last_error.restype = ctypes.c_char_p
+        L.rtamd_context_set_stream.argtypes = [vp, vp]
+        L.rtamd_context_set_stream.restype = ctypes.c_int
+        L.rtamd_synchronize.argtypes = [vp]
+        L.rtamd_synchronize.restype = ctypes.c_int
+        L.rtamd_upload_scene.argtypes = [vp, ctypes.POINTER(SceneDesc)]
+        L.rtamd_upload_scene.restype = ctypes.c_int
+        L.rtamd_upload_texture.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint32, ctypes.c_uint32]
+        L.rtamd_upload_texture.restype = ctypes.c_int
+        for name in ("rtamd_render", "rtamd_render_device"):
+            getattr(L, name).argtypes = [vp, ctypes.POINTER(FrameDesc), ctypes.POINTER(FrameOut)]
+            getattr(L, name).restype = ctypes.c_int
+        for name in ("rtamd_trace", "rtamd_trace_device"):
+            getattr(L, name).argtypes = [vp, ctypes.c_uint64, vp, vp, vp]
+            getattr(L, name).restype = ctypes.c_int
+        for name in ("rtamd_generate_rays", "rtamd_generate_rays_device"):
+            getattr(L, name).argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, c_float_p, ctypes.c_float, ctypes.c_float, vp]
+            getattr(L, name).restype = ctypes.c_int
+        L.rtamd_tiles_per_rank.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+        L.rtamd_tiles_per_rank.restype = ctypes.c_uint32
+        L.rtamd_assemble_tiles_device.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp]
+        L.rtamd_assemble_tiles_device.restype = ctypes.c_int
+        L.rtamd_get_scene_info.argtypes = [vp, ctypes.POINTER(SceneInfo)]
+        L.rtamd_get_scene_info.restype = ctypes.c_int
+        L.rtamd_last_kernel_ms.argtypes = [vp, c_float_p]
+        L.rtamd_last_kernel_ms.restype = ctypes.c_int
+        L.rtamd_set_kernel_variant.argtypes = [vp, ctypes.c_int]
+        L.rtamd_set_kernel_variant.restype = ctypes.c_int
+        L.rtamd_version.argtypes = []
+        L.rtamd_version.restype = ctypes.c_char_p
+        _device = L
+    return _device

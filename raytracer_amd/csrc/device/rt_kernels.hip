@@ -1,0 +1,601 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels for the ray-tracing hot path.
+//
+// What is implemented (reference file:line each device function follows):
+//   aabb_dist()         intersectAABB       res/shaders/ray_trace_and_shade.frag:53-61
+//   tri_test()          intersectTriangle   ray_trace_and_shade.frag:63-87
+//   traversal loops     traverseBVH         ray_trace_and_shade.frag:112-151
+//                                           (= ray_trace/ray_trace.frag:104-129)
+//   shade_primary()     main (hit branch)   ray_trace_and_shade.frag:206-231
+//   skybox()            skybox + constants  ray_trace_and_shade.frag:180-193
+//   gen_primary_dir()   ray_create.frag:12 with util/quad-11.vert:8
+//   sample_albedo()     texture() on RGBA8/LINEAR/REPEAT (src/gl_wrapper/texture.rs:11-42)
+//
+// Numerical contract (bit-exact hit records): the file is compiled with
+// -ffp-contract=off (no FMA), correctly rounded divide/sqrt and f32 denormals
+// flushed, and dot products are summed z,y,x — the arithmetic Mesa llvmpipe
+// executes for the unmodified shader (the pinned reference).
+// The traversal keeps the reference's binary tree and visiting order (near child
+// first, child b first on ties, current-t culling, ascending triangles, strict <).
+//
+// Execution model: one wave64 = 64 independent rays.  k_persistent is the
+// production kernel: waves stay resident, pull 8x8-pixel work items from atomic
+// queues (one queue per XCD-sized slice of the item list, with stealing) and
+// re-fill idle lanes (ballot + mbcnt compaction of the pending-pixel pool) when
+// fewer than `dyn_thresh` lanes are still traversing.  k_static (one lane per
+// pixel, no re-fill) is kept as the A/B baseline.  Per-lane traversal stacks live
+// in LDS ([entry][thread], conflict-free for ds_read/write_b32) and spill to
+// scratch beyond LDS_STACK_ENTRIES.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_layout.h"
+
+namespace rtamd {
+
+constexpr float MISS = 1e30f;          // ray_trace_and_shade.frag:10
+constexpr float EPSILON = 0.000001f;   // :11
+constexpr float T_PRIMARY0 = 1000000.0f;  // :199,211
+constexpr float T_HIT_LIMIT = 1000.0f;    // :206,219
+constexpr int BLOCK = 256;
+
+struct SceneDev {
+    const WideNode *nodes;
+    const TriRecord *tris;
+    const BigLeaf *big;
+    const RefTriangle *tri_idx;   // reference 16-byte records (vertex indices + mat_idx)
+    const float *normals;         // 3 per vertex or nullptr
+    const float *texcoords;       // 2 per vertex or nullptr
+    const uint32_t *tex[2];       // RGBA8 texels, row-major, first row first
+    int32_t tex_w[2], tex_h[2];
+    float root_box[6];
+    uint32_t root_ref;
+};
+
+struct JobParams {
+    // fused render
+    uint32_t width, height;
+    const float *dir, *org;       // nullptr dir => generate from camera
+    float ipv[16];
+    float near_, far_;
+    float cam[3];
+    uint32_t has_tc, has_n;
+    uint32_t rank, world;
+    uint32_t tiles_x;
+    float *rgba;
+    uint32_t *hit_id;
+    float *hit_t;
+    uint32_t *counts;
+    // trace
+    uint64_t n_rays;
+    float *hits;
+    // scheduling
+    uint32_t n_items;             // work items of 64 pixels / rays
+    uint32_t *queues;             // n_queues counters, 16 dwords apart
+    uint32_t n_queues;
+    uint32_t dyn_thresh;
+};
+
+// ---------------------------------------------------------------------------
+// arithmetic helpers (evaluation order fixed, see header comment)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float dot_zyx(float ax, float ay, float az, float bx, float by, float bz) {
+    return (az * bz + ay * by) + ax * bx;
+}
+
+struct Ray { float ox, oy, oz, dx, dy, dz, rx, ry, rz; };
+
+__device__ __forceinline__ void set_ray(Ray &r, float ox, float oy, float oz, float dx, float dy, float dz) {
+    r.ox = ox; r.oy = oy; r.oz = oz;
+    r.dx = dx; r.dy = dy; r.dz = dz;
+    r.rx = 1.0f / dx; r.ry = 1.0f / dy; r.rz = 1.0f / dz;  // `1 / dir`, :204
+}
+
+// intersectAABB: tmin, or MISS when !(tmax >= tmin && tmin < t && tmax > 0)
+__device__ __forceinline__ float aabb_dist(const Ray &r, float minx, float miny, float minz, float maxx, float maxy,
+                                           float maxz, float t) {
+    float tx1 = (minx - r.ox) * r.rx, tx2 = (maxx - r.ox) * r.rx;
+    float tmin = fminf(tx1, tx2), tmax = fmaxf(tx1, tx2);
+    float ty1 = (miny - r.oy) * r.ry, ty2 = (maxy - r.oy) * r.ry;
+    tmin = fmaxf(tmin, fminf(ty1, ty2)); tmax = fminf(tmax, fmaxf(ty1, ty2));
+    float tz1 = (minz - r.oz) * r.rz, tz2 = (maxz - r.oz) * r.rz;
+    tmin = fmaxf(tmin, fminf(tz1, tz2)); tmax = fminf(tmax, fmaxf(tz1, tz2));
+    return (tmax >= tmin && tmin < t && tmax > 0.0f) ? tmin : MISS;
+}
+
+// intersectTriangle on a precomputed-edge record, evaluated branch-free: every
+// reject test of :72,78,83 and the caller's accept test :131 are folded into one
+// predicate, so lanes of a wave never diverge inside a triangle test.
+__device__ __forceinline__ void tri_test(const Ray &r, const TriRecord *__restrict__ rec, uint32_t i, float &best_t,
+                                         uint32_t &best_idx, float &best_u, float &best_v) {
+    const float4 r0 = *reinterpret_cast<const float4 *>(&rec[i].p0[0]);
+    const float4 r1 = *reinterpret_cast<const float4 *>(&rec[i].e1[1]);
+    const float r2 = rec[i].e2[2];
+    const float p0x = r0.x, p0y = r0.y, p0z = r0.z;
+    const float e1x = r0.w, e1y = r1.x, e1z = r1.y;
+    const float e2x = r1.z, e2y = r1.w, e2z = r2;
+    // h = cross(dir, edge2)
+    float hx = r.dy * e2z - e2y * r.dz;
+    float hy = r.dz * e2x - e2z * r.dx;
+    float hz = r.dx * e2y - e2x * r.dy;
+    float a = dot_zyx(e1x, e1y, e1z, hx, hy, hz);
+    bool ok = !(fabsf(a) < EPSILON);
+    float f = 1.0f / a;
+    float sx = r.ox - p0x, sy = r.oy - p0y, sz = r.oz - p0z;
+    float u = f * dot_zyx(sx, sy, sz, hx, hy, hz);
+    ok = ok && !(u < 0.0f || u > 1.0f);
+    // q = cross(s, edge1)
+    float qx = sy * e1z - e1y * sz;
+    float qy = sz * e1x - e1z * sx;
+    float qz = sx * e1y - e1x * sy;
+    float v = f * dot_zyx(r.dx, r.dy, r.dz, qx, qy, qz);
+    ok = ok && !(v < 0.0f || u + v > 1.0f);
+    float t = f * dot_zyx(e2x, e2y, e2z, qx, qy, qz);
+    ok = ok && (t > EPSILON && t < best_t);
+    if (ok) { best_t = t; best_idx = i; best_u = u; best_v = v; }
+}
+
+// ---------------------------------------------------------------------------
+// per-lane traversal state
+// ---------------------------------------------------------------------------
+struct Trav {
+    Ray ray;
+    float t;
+    uint32_t idx;
+    float u, v;
+    uint32_t cur;   // node reference being visited, REF_NONE when the traversal is finished
+    uint32_t sp;    // number of deferred references on this lane's stack
+};
+
+__device__ __forceinline__ void stack_push(uint32_t *lds, uint32_t *spill, uint32_t tid, uint32_t &sp, uint32_t v) {
+    if (sp < (uint32_t)LDS_STACK_ENTRIES) lds[sp * BLOCK + tid] = v;
+    else if (sp < (uint32_t)MAX_STACK_ENTRIES) spill[sp - LDS_STACK_ENTRIES] = v;
+    sp++;
+}
+__device__ __forceinline__ uint32_t stack_pop(const uint32_t *lds, const uint32_t *spill, uint32_t tid, uint32_t &sp) {
+    sp--;
+    if (sp < (uint32_t)LDS_STACK_ENTRIES) return lds[sp * BLOCK + tid];
+    if (sp < (uint32_t)MAX_STACK_ENTRIES) return spill[sp - LDS_STACK_ENTRIES];
+    return REF_NONE;
+}
+
+// Start a traversal: the root box is tested once (:115-117).
+template <bool COUNT>
+__device__ __forceinline__ void trav_begin(const SceneDev &s, Trav &tr, float t0, uint32_t &nbox) {
+    tr.t = t0; tr.idx = 0; tr.u = 0.0f; tr.v = 0.0f; tr.sp = 0;
+    if (COUNT) nbox++;
+    float d = aabb_dist(tr.ray, s.root_box[0], s.root_box[1], s.root_box[2], s.root_box[3], s.root_box[4], s.root_box[5], tr.t);
+    tr.cur = (d == MISS) ? REF_NONE : s.root_ref;
+}
+
+// One inner-node visit (:138-148): test both children with the current t, descend
+// into the nearer hit child, defer the other.  Equal distances: child b first.
+template <bool COUNT>
+__device__ __forceinline__ void trav_inner(const SceneDev &s, Trav &tr, uint32_t *lds, uint32_t *spill, uint32_t tid, uint32_t &nbox) {
+    const float4 *np = reinterpret_cast<const float4 *>(&s.nodes[tr.cur]);
+    const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+    const uint2 refs = *reinterpret_cast<const uint2 *>(&np[3]);
+    if (COUNT) nbox += 2;
+    float dist0 = aabb_dist(tr.ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tr.t);
+    float dist1 = aabb_dist(tr.ray, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr.t);
+    bool hit0 = dist0 != MISS, hit1 = dist1 != MISS;
+    bool a_first = dist0 < dist1;
+    uint32_t first = a_first ? refs.x : refs.y, second = a_first ? refs.y : refs.x;
+    bool hit_first = a_first ? hit0 : hit1, hit_second = a_first ? hit1 : hit0;
+    if (hit_first) {
+        tr.cur = first;
+        if (hit_second) stack_push(lds, spill, tid, tr.sp, second);
+    } else if (hit_second) {
+        tr.cur = second;
+    } else {
+        tr.cur = tr.sp ? stack_pop(lds, spill, tid, tr.sp) : REF_NONE;
+    }
+}
+
+// One leaf visit (:122-136): all triangles in ascending order, then pop.
+template <bool COUNT>
+__device__ __forceinline__ void trav_leaf(const SceneDev &s, Trav &tr, const uint32_t *lds, const uint32_t *spill, uint32_t tid, uint32_t &ntri) {
+    uint32_t ref = tr.cur;
+    uint32_t count = (ref >> REF_COUNT_SHIFT) & 15u;
+    uint32_t first = ref & REF_FIRST_MASK;
+    if (count == 0) {
+        BigLeaf bl = s.big[first];
+        first = bl.first; count = bl.count;
+    }
+    if (COUNT) ntri += count;
+    for (uint32_t i = first; i < first + count; i++) tri_test(tr.ray, s.tris, i, tr.t, tr.idx, tr.u, tr.v);
+    tr.cur = tr.sp ? stack_pop(lds, spill, tid, tr.sp) : REF_NONE;
+}
+
+__device__ __forceinline__ bool ref_is_inner(uint32_t ref) { return (ref & REF_LEAF_BIT) == 0 && ref != REF_NONE; }
+
+// Run this lane's traversal to completion (static kernel).
+template <bool COUNT>
+__device__ __forceinline__ void trav_run(const SceneDev &s, Trav &tr, uint32_t *lds, uint32_t *spill, uint32_t tid, uint32_t &nbox, uint32_t &ntri) {
+    while (tr.cur != REF_NONE) {
+        while (ref_is_inner(tr.cur)) trav_inner<COUNT>(s, tr, lds, spill, tid, nbox);
+        if (tr.cur != REF_NONE) trav_leaf<COUNT>(s, tr, lds, spill, tid, ntri);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// shading
+// ---------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 sun_dir() {
+    // normalize(vec3(1,2,1)) as the GLSL compiler folds it: v * (1/sqrt(6))
+    const float inv = 1.0f / sqrtf(6.0f);
+    return V3{1.0f * inv, 2.0f * inv, 1.0f * inv};
+}
+
+__device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+// pow(x,y) is undefined in GLSL for x < 0; the pinned reference yields NaN which the
+// following clamp turns into 0 — restated as "negative base => 0".
+__device__ __forceinline__ float pow_clamp01(float x, float y) { return (x >= 0.0f) ? clamp01(powf(x, y)) : 0.0f; }
+
+__device__ __forceinline__ V3 skybox(float dx, float dy, float dz) {
+    const V3 sd = sun_dir();
+    float sun_fac = pow_clamp01(dot_zyx(dx, dy, dz, sd.x, sd.y, sd.z), 200.0f);
+    float sky_fac = (dy + 1.0f) * 0.5f;
+    float inv_fac = 1.0f - sky_fac;
+    return V3{(0.5f * sky_fac + 0.2f * inv_fac) + 1.0f * sun_fac,
+              (0.7f * sky_fac + 0.5f * inv_fac) + 0.97f * sun_fac,
+              (0.9f * sky_fac + 0.8f * inv_fac) + 0.86f * sun_fac};
+}
+
+__device__ __forceinline__ int wrap_repeat(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+
+// LINEAR min/mag, REPEAT, single level, RGBA8 unorm (GL 4.6 spec 8.14.2: texel
+// centres at i+0.5, weights frac(u*W-0.5)).
+__device__ __forceinline__ V3 sample_albedo(const uint32_t *__restrict__ tex, int W, int H, float s, float t) {
+    float u = s * (float)W - 0.5f, v = t * (float)H - 0.5f;
+    float fu = floorf(u), fv = floorf(v);
+    float a = u - fu, b = v - fv;
+    int i0 = wrap_repeat((int)fu, W), j0 = wrap_repeat((int)fv, H);
+    int i1 = i0 + 1 == W ? 0 : i0 + 1, j1 = j0 + 1 == H ? 0 : j0 + 1;
+    uint32_t t00 = tex[(size_t)j0 * W + i0], t10 = tex[(size_t)j0 * W + i1];
+    uint32_t t01 = tex[(size_t)j1 * W + i0], t11 = tex[(size_t)j1 * W + i1];
+    float c[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float c00 = (float)((t00 >> (8 * k)) & 255u) / 255.0f, c10 = (float)((t10 >> (8 * k)) & 255u) / 255.0f;
+        float c01 = (float)((t01 >> (8 * k)) & 255u) / 255.0f, c11 = (float)((t11 >> (8 * k)) & 255u) / 255.0f;
+        float top = c00 + a * (c10 - c00);
+        float bot = c01 + a * (c11 - c01);
+        c[k] = top + b * (bot - top);
+    }
+    return V3{c[0], c[1], c[2]};
+}
+
+// Hit branch of main (:207-229) up to the shadow traversal: computes the shading
+// normal, the two candidate colours (lit / in shadow) and the shadow ray.
+__device__ __forceinline__ void shade_primary(const SceneDev &s, const JobParams &p, const Trav &tr, V3 &col_shadow, V3 &col_lit, Ray &shadow_ray) {
+    const RefTriangle tri = s.tri_idx[tr.idx];
+    const float u = tr.u, v = tr.v;
+    const float w = 1.0f - u - v;
+    float nx, ny, nz;
+    if (p.has_n) {
+        const float *n0 = s.normals + 3 * (size_t)tri.p0, *n1 = s.normals + 3 * (size_t)tri.p1, *n2 = s.normals + 3 * (size_t)tri.p2;
+        nx = (n1[0] * u + n2[0] * v) + n0[0] * w;
+        ny = (n1[1] * u + n2[1] * v) + n0[1] * w;
+        nz = (n1[2] * u + n2[2] * v) + n0[2] * w;
+    } else {
+        const TriRecord &rec = s.tris[tr.idx];   // cross(v1 - v0, v2 - v0), :176
+        nx = rec.e1[1] * rec.e2[2] - rec.e2[1] * rec.e1[2];
+        ny = rec.e1[2] * rec.e2[0] - rec.e2[2] * rec.e1[0];
+        nz = rec.e1[0] * rec.e2[1] - rec.e2[0] * rec.e1[1];
+    }
+    {   // normalize(v) = v * (1 / sqrt(dot(v,v)))
+        float inv = 1.0f / sqrtf(dot_zyx(nx, ny, nz, nx, ny, nz));
+        nx *= inv; ny *= inv; nz *= inv;
+    }
+    float tcx = 0.0f, tcy = 0.0f;
+    if (p.has_tc) {
+        const float *t0 = s.texcoords + 2 * (size_t)tri.p0, *t1 = s.texcoords + 2 * (size_t)tri.p1, *t2 = s.texcoords + 2 * (size_t)tri.p2;
+        tcx = (t1[0] * u + t2[0] * v) + t0[0] * w;
+        tcy = (t1[1] * u + t2[1] * v) + t0[1] * w;
+    }
+    const Ray &r = tr.ray;
+    // reflect(I, N) = I - 2 * dot(N, I) * N
+    float two_d = 2.0f * dot_zyx(nx, ny, nz, r.dx, r.dy, r.dz);
+    float rfx = r.dx - nx * two_d, rfy = r.dy - ny * two_d, rfz = r.dz - nz * two_d;
+    const V3 sd = sun_dir();
+    // shadow ray (:214-217): org + dir * t + normal * 0.0001
+    set_ray(shadow_ray, (r.ox + r.dx * tr.t) + nx * 0.0001f, (r.oy + r.dy * tr.t) + ny * 0.0001f, (r.oz + r.dz * tr.t) + nz * 0.0001f,
+            sd.x, sd.y, sd.z);
+    const uint32_t m = tri.mat_idx & 1u;
+    V3 albedo = sample_albedo(s.tex[m], s.tex_w[m], s.tex_h[m], tcx, -tcy);
+    V3 sky = skybox(nx, ny, nz);
+    float ndl = clamp01(dot_zyx(nx, ny, nz, sd.x, sd.y, sd.z));
+    float spec = pow_clamp01(dot_zyx(rfx, rfy, rfz, sd.x, sd.y, sd.z), 30.0f);
+    V3 ambient{(albedo.x * sky.x) * 0.5f, (albedo.y * sky.y) * 0.5f, (albedo.z * sky.z) * 0.5f};
+    V3 diffuse{((albedo.x * 1.0f) * ndl) * 0.8f, ((albedo.y * 0.97f) * ndl) * 0.8f, ((albedo.z * 0.86f) * ndl) * 0.8f};
+    V3 specular{(1.0f * spec) * 0.4f, (0.97f * spec) * 0.4f, (0.86f * spec) * 0.4f};
+    col_lit = V3{(ambient.x + diffuse.x) + specular.x, (ambient.y + diffuse.y) + specular.y, (ambient.z + diffuse.z) + specular.z};
+    // in shadow: diffuse *= 0, specular *= 0 (:226-229)
+    col_shadow = V3{(ambient.x + diffuse.x * 0.0f) + specular.x * 0.0f, (ambient.y + diffuse.y * 0.0f) + specular.y * 0.0f,
+                    (ambient.z + diffuse.z * 0.0f) + specular.z * 0.0f};
+}
+
+// ray_create.frag:12 at the centre of pixel (px,py); row 0 = bottom.
+__device__ __forceinline__ void gen_primary_dir(const float *__restrict__ m, float near_, float far_, uint32_t width, uint32_t height,
+                                                uint32_t px, uint32_t py, float &dx, float &dy, float &dz) {
+    float x = ((float)px + 0.5f) / (float)width * 2.0f - 1.0f;
+    float y = ((float)py + 0.5f) / (float)height * 2.0f - 1.0f;
+    float v0 = x * far_ - x * near_;
+    float v1 = y * far_ - y * near_;
+    float v2 = 1.0f * far_ - (-1.0f) * near_;
+    float v3 = 1.0f * far_ - 1.0f * near_;
+    float d0 = ((m[0] * v0 + m[4] * v1) + m[8] * v2) + m[12] * v3;
+    float d1 = ((m[1] * v0 + m[5] * v1) + m[9] * v2) + m[13] * v3;
+    float d2 = ((m[2] * v0 + m[6] * v1) + m[10] * v2) + m[14] * v3;
+    float inv = 1.0f / sqrtf(dot_zyx(d0, d1, d2, d0, d1, d2));
+    dx = d0 * inv; dy = d1 * inv; dz = d2 * inv;
+}
+
+// ---------------------------------------------------------------------------
+// work-item geometry: item -> 8x8 pixel block of a 32x32 tile owned by this rank
+// ---------------------------------------------------------------------------
+struct PixelRef { uint32_t ray_index; uint32_t out_index; bool valid; uint32_t px, py; };
+
+__device__ __forceinline__ PixelRef item_pixel(const JobParams &p, uint32_t item, uint32_t l) {
+    uint32_t j = item >> 4, sub = item & 15u;
+    uint32_t g = j * p.world + p.rank;
+    uint32_t tx = g % p.tiles_x, ty = g / p.tiles_x;
+    uint32_t x = (tx * 4u + (sub & 3u)) * 8u + (l & 7u);
+    uint32_t y = (ty * 4u + (sub >> 2)) * 8u + (l >> 3);
+    PixelRef r;
+    r.px = x; r.py = y;
+    r.valid = x < p.width && y < p.height;
+    r.ray_index = y * p.width + x;
+    r.out_index = (p.world == 1u) ? r.ray_index : j * (RTAMD_TILE_PIXELS) + ((y & 31u) * 32u + (x & 31u));
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// queues: n_queues counters (64 bytes apart); queue k serves items
+// [k*n/nq, (k+1)*n/nq).  A wave starts on the queue of its XCD and steals from
+// the others when its own is empty, so placement only affects L2 locality.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
+    return v & 7u;
+}
+
+__device__ __forceinline__ uint32_t fetch_item(const JobParams &p, uint32_t home, uint32_t &tried, uint32_t lane) {
+    while (tried < p.n_queues) {
+        uint32_t k = home + tried;
+        if (k >= p.n_queues) k -= p.n_queues;
+        uint32_t lo = (uint32_t)(((uint64_t)p.n_items * k) / p.n_queues);
+        uint32_t hi = (uint32_t)(((uint64_t)p.n_items * (k + 1)) / p.n_queues);
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(&p.queues[k * 16u], 1u);
+        v = __builtin_amdgcn_readfirstlane(v);
+        if (v < hi - lo) return lo + v;
+        tried++;
+    }
+    return 0xFFFFFFFFu;
+}
+
+enum : uint32_t { PH_IDLE = 0, PH_PRIMARY = 1, PH_SHADOW = 2 };
+enum : int { MODE_FUSED = 0, MODE_TRACE = 1 };
+
+// ---------------------------------------------------------------------------
+// k_persistent — production kernel
+// ---------------------------------------------------------------------------
+template <int MODE, bool COUNT>
+__global__ void __launch_bounds__(BLOCK) k_persistent(const SceneDev s, const JobParams p) {
+    __shared__ uint32_t lds_stack[LDS_STACK_ENTRIES * BLOCK];
+    uint32_t spill[SPILL_STACK_ENTRIES];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+
+    // wave-uniform pool of pending pixels / rays: item `pool_item`, lanes [pool_next, 64)
+    uint32_t pool_item = 0, pool_next = 64;
+    bool drained = false;
+    uint32_t tried = 0;
+    const uint32_t home = p.n_queues > 1 ? xcc_id() % p.n_queues : 0u;
+
+    uint32_t phase = PH_IDLE;
+    Trav tr;
+    tr.cur = REF_NONE; tr.sp = 0; tr.t = 0; tr.idx = 0; tr.u = tr.v = 0;
+    tr.ray = Ray{0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t out_index = 0;
+    uint32_t nbox = 0, ntri = 0;
+    float prim_t = 0.0f;
+    uint32_t prim_idx = 0;
+    V3 col_shadow{0, 0, 0}, col_lit{0, 0, 0};
+
+    for (;;) {
+        // ---- re-fill idle lanes from the pool (ballot + mbcnt compaction) ----
+        unsigned long long idle = __ballot(phase == PH_IDLE);
+        while (idle != 0ull && !drained) {
+            if (pool_next >= 64u) {
+                uint32_t item = fetch_item(p, home, tried, lane);
+                if (item == 0xFFFFFFFFu) { drained = true; break; }
+                pool_item = item; pool_next = 0;
+            }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const uint32_t avail = 64u - pool_next;
+            if (phase == PH_IDLE && rank < avail) {
+                const uint32_t l = pool_next + rank;
+                if (MODE == MODE_FUSED) {
+                    PixelRef pr = item_pixel(p, pool_item, l);
+                    if (pr.valid) {
+                        float dx, dy, dz, ox, oy, oz;
+                        if (p.dir) {
+                            const float *d = p.dir + 3 * (size_t)pr.ray_index, *o = p.org + 3 * (size_t)pr.ray_index;
+                            dx = d[0]; dy = d[1]; dz = d[2]; ox = o[0]; oy = o[1]; oz = o[2];
+                        } else {
+                            gen_primary_dir(p.ipv, p.near_, p.far_, p.width, p.height, pr.px, pr.py, dx, dy, dz);
+                            ox = p.cam[0]; oy = p.cam[1]; oz = p.cam[2];
+                        }
+                        set_ray(tr.ray, ox, oy, oz, dx, dy, dz);
+                        out_index = pr.out_index;
+                        nbox = 0; ntri = 0;
+                        trav_begin<COUNT>(s, tr, T_PRIMARY0, nbox);
+                        phase = PH_PRIMARY;
+                    }
+                } else {
+                    const uint64_t ri = (uint64_t)pool_item * 64u + l;
+                    if (ri < p.n_rays) {
+                        const float *d = p.dir + 3 * ri, *o = p.org + 3 * ri;
+                        out_index = (uint32_t)ri;
+                        nbox = 0; ntri = 0;
+                        if (d[0] == 0.0f && d[1] == 0.0f && d[2] == 0.0f) {
+                            // NO_RAY: the fragment is discarded, the target keeps its clear value
+                            *reinterpret_cast<float4 *>(p.hits + 4 * ri) = make_float4(MISS, 0.0f, 0.0f, 0.0f);
+                            if (COUNT && p.counts) { p.counts[2 * ri] = 0; p.counts[2 * ri + 1] = 0; }
+                        } else {
+                            set_ray(tr.ray, o[0], o[1], o[2], d[0], d[1], d[2]);
+                            trav_begin<COUNT>(s, tr, MISS, nbox);
+                            phase = PH_PRIMARY;
+                        }
+                    }
+                }
+            }
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            pool_next += n_idle < avail ? n_idle : avail;
+            idle = __ballot(phase == PH_IDLE);
+        }
+        if (__ballot(phase != PH_IDLE) == 0ull) break;
+
+        // ---- traverse until too few lanes are still busy ----
+        const uint32_t thresh = drained ? 1u : p.dyn_thresh;
+        for (;;) {
+            const bool busy = tr.cur != REF_NONE;
+            if ((uint32_t)__popcll(__ballot(busy)) < thresh) break;
+            if (busy) {
+                while (ref_is_inner(tr.cur)) trav_inner<COUNT>(s, tr, lds_stack, spill, tid, nbox);
+                if (tr.cur != REF_NONE) trav_leaf<COUNT>(s, tr, lds_stack, spill, tid, ntri);
+            }
+        }
+
+        // ---- retire finished traversals ----
+        if (phase != PH_IDLE && tr.cur == REF_NONE) {
+            if (MODE == MODE_TRACE) {
+                // ray_trace.frag:139-142
+                *reinterpret_cast<float4 *>(p.hits + 4 * (size_t)out_index) = make_float4(tr.t, tr.u, tr.v, __uint_as_float(tr.idx));
+                if (COUNT && p.counts) { p.counts[2 * (size_t)out_index] = nbox; p.counts[2 * (size_t)out_index + 1] = ntri; }
+                phase = PH_IDLE;
+            } else if (phase == PH_PRIMARY) {
+                prim_t = tr.t; prim_idx = tr.idx;
+                if (tr.t < T_HIT_LIMIT) {
+                    Ray sray;
+                    shade_primary(s, p, tr, col_shadow, col_lit, sray);
+                    tr.ray = sray;
+                    trav_begin<COUNT>(s, tr, T_PRIMARY0, nbox);
+                    phase = PH_SHADOW;
+                } else {
+                    V3 c = skybox(tr.ray.dx, tr.ray.dy, tr.ray.dz);
+                    if (p.rgba) *reinterpret_cast<float4 *>(p.rgba + 4 * (size_t)out_index) = make_float4(c.x, c.y, c.z, 1.0f);
+                    if (p.hit_id) p.hit_id[out_index] = 0xFFFFFFFFu;
+                    if (p.hit_t) p.hit_t[out_index] = prim_t;
+                    if (COUNT && p.counts) { p.counts[2 * (size_t)out_index] = nbox; p.counts[2 * (size_t)out_index + 1] = ntri; }
+                    phase = PH_IDLE;
+                }
+            } else {  // PH_SHADOW finished
+                const bool shadow = tr.t < T_HIT_LIMIT;
+                V3 c = shadow ? col_shadow : col_lit;
+                if (p.rgba) *reinterpret_cast<float4 *>(p.rgba + 4 * (size_t)out_index) = make_float4(c.x, c.y, c.z, 1.0f);
+                if (p.hit_id) p.hit_id[out_index] = prim_idx;
+                if (p.hit_t) p.hit_t[out_index] = prim_t;
+                if (COUNT && p.counts) { p.counts[2 * (size_t)out_index] = nbox; p.counts[2 * (size_t)out_index + 1] = ntri; }
+                phase = PH_IDLE;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_static — A/B baseline: one lane per pixel / ray, one 64-lane item per wave,
+// no persistence, no re-fill.  Same device functions, same results.
+// ---------------------------------------------------------------------------
+template <int MODE, bool COUNT>
+__global__ void __launch_bounds__(BLOCK) k_static(const SceneDev s, const JobParams p) {
+    __shared__ uint32_t lds_stack[LDS_STACK_ENTRIES * BLOCK];
+    uint32_t spill[SPILL_STACK_ENTRIES];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t item = blockIdx.x * (BLOCK / 64) + (tid >> 6);
+    if (item >= p.n_items) return;
+    Trav tr;
+    uint32_t nbox = 0, ntri = 0;
+    if (MODE == MODE_TRACE) {
+        const uint64_t ri = (uint64_t)item * 64u + lane;
+        if (ri >= p.n_rays) return;
+        const float *d = p.dir + 3 * ri, *o = p.org + 3 * ri;
+        if (d[0] == 0.0f && d[1] == 0.0f && d[2] == 0.0f) {
+            *reinterpret_cast<float4 *>(p.hits + 4 * ri) = make_float4(MISS, 0.0f, 0.0f, 0.0f);
+            if (COUNT && p.counts) { p.counts[2 * ri] = 0; p.counts[2 * ri + 1] = 0; }
+            return;
+        }
+        set_ray(tr.ray, o[0], o[1], o[2], d[0], d[1], d[2]);
+        trav_begin<COUNT>(s, tr, MISS, nbox);
+        trav_run<COUNT>(s, tr, lds_stack, spill, tid, nbox, ntri);
+        *reinterpret_cast<float4 *>(p.hits + 4 * ri) = make_float4(tr.t, tr.u, tr.v, __uint_as_float(tr.idx));
+        if (COUNT && p.counts) { p.counts[2 * ri] = nbox; p.counts[2 * ri + 1] = ntri; }
+        return;
+    }
+    PixelRef pr = item_pixel(p, item, lane);
+    if (!pr.valid) return;
+    float dx, dy, dz, ox, oy, oz;
+    if (p.dir) {
+        const float *d = p.dir + 3 * (size_t)pr.ray_index, *o = p.org + 3 * (size_t)pr.ray_index;
+        dx = d[0]; dy = d[1]; dz = d[2]; ox = o[0]; oy = o[1]; oz = o[2];
+    } else {
+        gen_primary_dir(p.ipv, p.near_, p.far_, p.width, p.height, pr.px, pr.py, dx, dy, dz);
+        ox = p.cam[0]; oy = p.cam[1]; oz = p.cam[2];
+    }
+    set_ray(tr.ray, ox, oy, oz, dx, dy, dz);
+    trav_begin<COUNT>(s, tr, T_PRIMARY0, nbox);
+    trav_run<COUNT>(s, tr, lds_stack, spill, tid, nbox, ntri);
+    const float prim_t = tr.t;
+    const uint32_t prim_idx = tr.idx;
+    V3 c;
+    uint32_t id = 0xFFFFFFFFu;
+    if (tr.t < T_HIT_LIMIT) {
+        V3 col_shadow, col_lit;
+        Ray sray;
+        shade_primary(s, p, tr, col_shadow, col_lit, sray);
+        tr.ray = sray;
+        trav_begin<COUNT>(s, tr, T_PRIMARY0, nbox);
+        trav_run<COUNT>(s, tr, lds_stack, spill, tid, nbox, ntri);
+        c = (tr.t < T_HIT_LIMIT) ? col_shadow : col_lit;
+        id = prim_idx;
+    } else {
+        c = skybox(dx, dy, dz);
+    }
+    if (p.rgba) *reinterpret_cast<float4 *>(p.rgba + 4 * (size_t)pr.out_index) = make_float4(c.x, c.y, c.z, 1.0f);
+    if (p.hit_id) p.hit_id[pr.out_index] = id;
+    if (p.hit_t) p.hit_t[pr.out_index] = prim_t;
+    if (COUNT && p.counts) { p.counts[2 * (size_t)pr.out_index] = nbox; p.counts[2 * (size_t)pr.out_index + 1] = ntri; }
+}
+
+// ---------------------------------------------------------------------------
+// small utility kernels
+// ---------------------------------------------------------------------------
+__global__ void k_generate_rays(const float *__restrict__ ipv16, float near_, float far_, uint32_t width, uint32_t height, float *__restrict__ dir_out) {
+    __shared__ float m[16];
+    if (threadIdx.x < 16) m[threadIdx.x] = ipv16[threadIdx.x];
+    __syncthreads();
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= width * height) return;
+    uint32_t px = i % width, py = i / width;
+    float dx, dy, dz;
+    gen_primary_dir(m, near_, far_, width, height, px, py, dx, dy, dz);
+    dir_out[3 * (size_t)i + 0] = dx; dir_out[3 * (size_t)i + 1] = dy; dir_out[3 * (size_t)i + 2] = dz;
+}
+
+// Root side of the gather: rank-major tile blocks -> scan-line frame.
+__global__ void k_assemble_tiles(const uint32_t *__restrict__ gathered, uint32_t width, uint32_t height, uint32_t world,
+                                 uint32_t tiles_x, uint32_t tiles_per_rank, uint32_t elems, uint32_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= width * height) return;
+    uint32_t x = i % width, y = i / width;
+    uint32_t g = (y >> 5) * tiles_x + (x >> 5);
+    uint32_t r = g % world, j = g / world;
+    size_t src = ((size_t)r * tiles_per_rank + j) * RTAMD_TILE_PIXELS + ((y & 31u) * 32u + (x & 31u));
+    for (uint32_t e = 0; e < elems; e++) out[(size_t)i * elems + e] = gathered[src * elems + e];
+}
+
+}  // namespace rtamd

@@ -1,0 +1,579 @@
+// C-ABI implementation (include/rtamd.h): context, scene upload + layout
+// conversion, kernel launches.  gfx950 only; no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../../include/rtamd.h"
+#include "rt_kernels.hip"
+
+using namespace rtamd;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+}  // namespace
+
+struct rtamd_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool ev_valid = false;
+    std::string err;
+    int variant = 0;
+    int num_cu = 0;
+    int persistent_blocks_per_cu[4] = {0, 0, 0, 0};  // [mode*2 + count]
+    // scene
+    bool has_scene = false;
+    DevBuf nodes, tris, big, tri_idx, normals, texcoords;
+    DevBuf tex[2];
+    int32_t tex_w[2] = {1, 1}, tex_h[2] = {1, 1};
+    DevBuf white;
+    DevBuf queues;
+    DevBuf ipv;  // 16 floats for k_generate_rays
+    SceneDev sdev{};
+    rtamd_scene_info info{};
+    uint32_t dyn_thresh = 40;
+    uint32_t n_queues = 8;
+};
+
+namespace {
+
+int fail(rtamd_context *ctx, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? RTAMD_ERR_OUT_OF_MEMORY : RTAMD_ERR_DEVICE, \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                            \
+    } while (0)
+
+int dev_alloc(rtamd_context *ctx, DevBuf &b, size_t bytes) {
+    b.release();
+    if (bytes == 0) bytes = 16;
+    HIP_TRY(ctx, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return RTAMD_OK;
+}
+
+int dev_upload(rtamd_context *ctx, DevBuf &b, const void *src, size_t bytes) {
+    int rc = dev_alloc(ctx, b, bytes);
+    if (rc) return rc;
+    if (bytes) HIP_TRY(ctx, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return RTAMD_OK;
+}
+
+// The pinned reference (llvmpipe) runs with denormals flushed (inputs and
+// results); the device kernels are compiled the same way.  Precomputed edges are
+// host arithmetic, so flush here explicitly.
+inline float ftz(float x) { return std::fabs(x) < 1.17549435e-38f ? std::copysign(0.0f, x) : x; }
+
+uint32_t n_tiles_of(uint32_t w, uint32_t h, uint32_t *tiles_x) {
+    uint32_t tx = (w + RTAMD_TILE_DIM - 1) / RTAMD_TILE_DIM, ty = (h + RTAMD_TILE_DIM - 1) / RTAMD_TILE_DIM;
+    if (tiles_x) *tiles_x = tx;
+    return tx * ty;
+}
+
+uint32_t local_tiles(uint32_t n_tiles, uint32_t rank, uint32_t world) {
+    return rank < n_tiles ? (n_tiles - rank + world - 1) / world : 0;
+}
+
+template <typename K>
+int query_blocks(rtamd_context *ctx, K kernel, int *out) {
+    int nb = 0;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, BLOCK, 0));
+    if (nb < 1) nb = 1;
+    *out = nb;
+    return RTAMD_OK;
+}
+
+int ensure_ctx_device(rtamd_context *ctx) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return RTAMD_OK;
+}
+
+// Launch the traversal kernel selected by (mode, count, variant) for `p`.
+int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
+    if (p.n_items == 0) return RTAMD_OK;
+    p.queues = (uint32_t *)ctx->queues.p;
+    p.n_queues = ctx->n_queues;
+    p.dyn_thresh = ctx->dyn_thresh;
+    hipStream_t st = ctx->stream;
+    const SceneDev &s = ctx->sdev;
+    if (ctx->variant == 0) HIP_TRY(ctx, hipMemsetAsync(ctx->queues.p, 0, ctx->queues.bytes, st));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_start, st));
+    if (ctx->variant == 0) {
+        int per_cu = ctx->persistent_blocks_per_cu[mode * 2 + (count ? 1 : 0)];
+        uint32_t grid = (uint32_t)(ctx->num_cu * per_cu);
+        uint32_t need = (p.n_items + (BLOCK / 64) - 1) / (BLOCK / 64);
+        if (grid > need) grid = need;
+        if (grid < 1) grid = 1;
+        if (mode == MODE_FUSED) {
+            if (count) hipLaunchKernelGGL((k_persistent<MODE_FUSED, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
+            else hipLaunchKernelGGL((k_persistent<MODE_FUSED, false>), dim3(grid), dim3(BLOCK), 0, st, s, p);
+        } else {
+            if (count) hipLaunchKernelGGL((k_persistent<MODE_TRACE, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
+            else hipLaunchKernelGGL((k_persistent<MODE_TRACE, false>), dim3(grid), dim3(BLOCK), 0, st, s, p);
+        }
+    } else {
+        uint32_t grid = (p.n_items + (BLOCK / 64) - 1) / (BLOCK / 64);
+        if (mode == MODE_FUSED) {
+            if (count) hipLaunchKernelGGL((k_static<MODE_FUSED, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
+            else hipLaunchKernelGGL((k_static<MODE_FUSED, false>), dim3(grid), dim3(BLOCK), 0, st, s, p);
+        } else {
+            if (count) hipLaunchKernelGGL((k_static<MODE_TRACE, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
+            else hipLaunchKernelGGL((k_static<MODE_TRACE, false>), dim3(grid), dim3(BLOCK), 0, st, s, p);
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, st));
+    ctx->ev_valid = true;
+    return RTAMD_OK;
+}
+
+int check_frame(rtamd_context *ctx, const rtamd_frame_desc *d, const rtamd_frame_out *o) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (!d || !o) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "frame descriptor / output is NULL");
+    if (!ctx->has_scene) return fail(ctx, RTAMD_ERR_NO_SCENE, "no scene uploaded");
+    if (d->width == 0 || d->height == 0) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "empty frame %ux%u", d->width, d->height);
+    if ((uint64_t)d->width * d->height > 0x7FFFFFFFull) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "frame too large");
+    if (d->tile_world == 0 || d->tile_rank >= d->tile_world)
+        return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "tile_rank %u / tile_world %u invalid", d->tile_rank, d->tile_world);
+    if ((d->dir == nullptr) != (d->org == nullptr)) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "dir and org must both be given or both be NULL");
+    if (d->has_tex_coords && !ctx->texcoords.p) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "has_tex_coords set but the scene has no tex_coords");
+    if (d->has_normals && !ctx->normals.p) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "has_normals set but the scene has no normals");
+    return RTAMD_OK;
+}
+
+void fill_job(const rtamd_context *ctx, const rtamd_frame_desc *d, const rtamd_frame_out *o, JobParams &p) {
+    std::memset(&p, 0, sizeof p);
+    p.width = d->width; p.height = d->height;
+    p.dir = d->dir; p.org = d->org;
+    std::memcpy(p.ipv, d->inv_proj_view, sizeof p.ipv);
+    p.near_ = d->near_plane; p.far_ = d->far_plane;
+    std::memcpy(p.cam, d->cam_pos, sizeof p.cam);
+    p.has_tc = d->has_tex_coords ? 1u : 0u;
+    p.has_n = d->has_normals ? 1u : 0u;
+    p.rank = d->tile_rank; p.world = d->tile_world;
+    uint32_t tiles_x = 0;
+    uint32_t n_tiles = n_tiles_of(d->width, d->height, &tiles_x);
+    p.tiles_x = tiles_x;
+    p.n_items = local_tiles(n_tiles, d->tile_rank, d->tile_world) * 16u;
+    p.rgba = o->rgba32f; p.hit_id = o->hit_id; p.hit_t = o->hit_t; p.counts = o->counts;
+    (void)ctx;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rtamd_version(void) { return "rtamd 0.1 (gfx950)"; }
+
+int rtamd_context_create(int device_ordinal, rtamd_context **out_ctx) {
+    if (!out_ctx) return fail(nullptr, RTAMD_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(nullptr, RTAMD_ERR_DEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(nullptr, RTAMD_ERR_INVALID_ARGUMENT, "device %d out of range (0..%d)", device_ordinal, n - 1);
+    rtamd_context *ctx = new (std::nothrow) rtamd_context();
+    if (!ctx) return fail(nullptr, RTAMD_ERR_OUT_OF_MEMORY, "out of host memory");
+    ctx->device = device_ordinal;
+    auto bail = [&](int code) { g_create_error = ctx->err; rtamd_context_destroy(ctx); return code; };
+    int rc;
+    if ((rc = ensure_ctx_device(ctx))) return bail(rc);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) { ctx->err = "hipGetDeviceProperties failed"; return bail(RTAMD_ERR_DEVICE); }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        ctx->err = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return bail(RTAMD_ERR_DEVICE);
+    }
+    ctx->num_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(RTAMD_ERR_DEVICE); }
+    ctx->stream = ctx->own_stream;
+    if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) { ctx->err = "hipEventCreate failed"; return bail(RTAMD_ERR_DEVICE); }
+    if ((rc = query_blocks(ctx, k_persistent<MODE_FUSED, false>, &ctx->persistent_blocks_per_cu[0]))) return bail(rc);
+    if ((rc = query_blocks(ctx, k_persistent<MODE_FUSED, true>, &ctx->persistent_blocks_per_cu[1]))) return bail(rc);
+    if ((rc = query_blocks(ctx, k_persistent<MODE_TRACE, false>, &ctx->persistent_blocks_per_cu[2]))) return bail(rc);
+    if ((rc = query_blocks(ctx, k_persistent<MODE_TRACE, true>, &ctx->persistent_blocks_per_cu[3]))) return bail(rc);
+    const uint32_t white = 0xFFFFFFFFu;
+    if ((rc = dev_upload(ctx, ctx->white, &white, 4))) return bail(rc);
+    if ((rc = dev_alloc(ctx, ctx->queues, 8 * 64))) return bail(rc);
+    if ((rc = dev_alloc(ctx, ctx->ipv, 64))) return bail(rc);
+    const char *env = std::getenv("RTAMD_DYN_THRESH");
+    if (env) { int v = std::atoi(env); if (v >= 1 && v <= 64) ctx->dyn_thresh = (uint32_t)v; }
+    env = std::getenv("RTAMD_NUM_QUEUES");
+    if (env) { int v = std::atoi(env); if (v >= 1 && v <= 8) ctx->n_queues = (uint32_t)v; }
+    *out_ctx = ctx;
+    return RTAMD_OK;
+}
+
+void rtamd_context_destroy(rtamd_context *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    ctx->nodes.release(); ctx->tris.release(); ctx->big.release(); ctx->tri_idx.release();
+    ctx->normals.release(); ctx->texcoords.release(); ctx->tex[0].release(); ctx->tex[1].release();
+    ctx->white.release(); ctx->queues.release(); ctx->ipv.release();
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char *rtamd_last_error(const rtamd_context *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rtamd_context_set_stream(rtamd_context *ctx, void *hip_stream) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return RTAMD_OK;
+}
+
+int rtamd_synchronize(rtamd_context *ctx) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    int rc = ensure_ctx_device(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RTAMD_OK;
+}
+
+int rtamd_set_kernel_variant(rtamd_context *ctx, int variant) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (variant != 0 && variant != 1) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "unknown kernel variant %d", variant);
+    ctx->variant = variant;
+    return RTAMD_OK;
+}
+
+int rtamd_upload_scene(rtamd_context *ctx, const rtamd_scene_desc *sc) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (!sc) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (!sc->nodes || !sc->triangles || !sc->positions || sc->node_count == 0 || sc->triangle_count == 0 || sc->vertex_count == 0)
+        return fail(ctx, RTAMD_ERR_EMPTY_SCENE, "empty scene (nodes %u, triangles %u, vertices %u)", sc->node_count, sc->triangle_count, sc->vertex_count);
+    if (sc->triangle_count > MAX_TRIANGLES) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "more than %u triangles are not supported", MAX_TRIANGLES);
+    int rc = ensure_ctx_device(ctx);
+    if (rc) return rc;
+    const RefNode *nodes = (const RefNode *)sc->nodes;
+    const RefTriangle *tris = (const RefTriangle *)sc->triangles;
+    const uint32_t n_nodes = sc->node_count, n_tris = sc->triangle_count, n_verts = sc->vertex_count;
+    try {
+        for (uint32_t i = 0; i < n_tris; i++)
+            if (tris[i].p0 >= n_verts || tris[i].p1 >= n_verts || tris[i].p2 >= n_verts)
+                return fail(ctx, RTAMD_ERR_MALFORMED_SCENE, "triangle %u references a vertex >= %u", i, n_verts);
+
+        // Walk the tree from the root: validates indices, rejects shared / cyclic
+        // nodes, measures depth, and marks the reachable inner nodes.
+        std::vector<uint8_t> state(n_nodes, 0);  // 1 = reachable inner, 2 = reachable leaf
+        std::vector<std::pair<uint32_t, uint32_t>> todo;
+        todo.emplace_back(0u, 0u);
+        uint32_t max_depth = 0;
+        while (!todo.empty()) {
+            auto [ni, depth] = todo.back();
+            todo.pop_back();
+            if (ni >= n_nodes) return fail(ctx, RTAMD_ERR_MALFORMED_SCENE, "node index %u out of range (%u nodes)", ni, n_nodes);
+            if (state[ni]) return fail(ctx, RTAMD_ERR_MALFORMED_SCENE, "node %u is reachable twice (not a tree)", ni);
+            if (depth > max_depth) max_depth = depth;
+            const RefNode &nd = nodes[ni];
+            if (nd.is_leaf) {
+                state[ni] = 2;
+                if ((uint64_t)nd.a + nd.b > n_tris) return fail(ctx, RTAMD_ERR_MALFORMED_SCENE, "leaf %u covers triangles [%u, %u+%u) beyond %u", ni, nd.a, nd.a, nd.b, n_tris);
+            } else {
+                state[ni] = 1;
+                todo.emplace_back(nd.b, depth + 1);
+                todo.emplace_back(nd.a, depth + 1);
+            }
+        }
+        if (max_depth > (uint32_t)MAX_STACK_ENTRIES)
+            return fail(ctx, RTAMD_ERR_MALFORMED_SCENE, "tree depth %u exceeds the supported traversal stack (%d; the reference shader's is 100)", max_depth, MAX_STACK_ENTRIES);
+
+        std::vector<uint32_t> inner_index(n_nodes, 0);
+        uint32_t n_inner = 0;
+        for (uint32_t i = 0; i < n_nodes; i++) if (state[i] == 1) inner_index[i] = n_inner++;
+
+        std::vector<BigLeaf> big;
+        auto make_ref = [&](uint32_t ni) -> uint32_t {
+            const RefNode &nd = nodes[ni];
+            if (!nd.is_leaf) return inner_index[ni];
+            if (nd.b >= 1 && nd.b <= REF_INLINE_MAX_COUNT) return REF_LEAF_BIT | (nd.b << REF_COUNT_SHIFT) | nd.a;
+            big.push_back(BigLeaf{nd.a, nd.b});
+            return REF_LEAF_BIT | (uint32_t)(big.size() - 1);
+        };
+
+        std::vector<WideNode> wide(n_inner ? n_inner : 1);
+        std::memset(wide.data(), 0, wide.size() * sizeof(WideNode));
+        for (uint32_t i = 0; i < n_nodes; i++) {
+            if (state[i] != 1) continue;
+            const RefNode &nd = nodes[i];
+            WideNode &w = wide[inner_index[i]];
+            const RefNode &ca = nodes[nd.a], &cb = nodes[nd.b];
+            for (int k = 0; k < 3; k++) {
+                w.a_min[k] = ca.bounds[k]; w.a_max[k] = ca.bounds[3 + k];
+                w.b_min[k] = cb.bounds[k]; w.b_max[k] = cb.bounds[3 + k];
+            }
+            w.ref_a = make_ref(nd.a);
+            w.ref_b = make_ref(nd.b);
+        }
+        if (big.size() > REF_FIRST_MASK) return fail(ctx, RTAMD_ERR_MALFORMED_SCENE, "too many oversized leaves");
+        const uint32_t root_ref = make_ref(0);
+
+        std::vector<TriRecord> recs(n_tris);
+        const float *pos = sc->positions;
+        for (uint32_t i = 0; i < n_tris; i++) {
+            const float *p0 = pos + 3 * (size_t)tris[i].p0, *p1 = pos + 3 * (size_t)tris[i].p1, *p2 = pos + 3 * (size_t)tris[i].p2;
+            TriRecord &r = recs[i];
+            for (int k = 0; k < 3; k++) {
+                float a = ftz(p0[k]);
+                r.p0[k] = a;
+                r.e1[k] = ftz(ftz(p1[k]) - a);  // edge1 = p1 - p0, ray_trace_and_shade.frag:66
+                r.e2[k] = ftz(ftz(p2[k]) - a);  // edge2 = p2 - p0, :67
+                r.pad[k] = 0.0f;
+            }
+        }
+
+        if ((rc = dev_upload(ctx, ctx->nodes, wide.data(), wide.size() * sizeof(WideNode)))) return rc;
+        if ((rc = dev_upload(ctx, ctx->tris, recs.data(), recs.size() * sizeof(TriRecord)))) return rc;
+        if ((rc = dev_upload(ctx, ctx->big, big.data(), big.size() * sizeof(BigLeaf)))) return rc;
+        if ((rc = dev_upload(ctx, ctx->tri_idx, tris, (size_t)n_tris * sizeof(RefTriangle)))) return rc;
+        ctx->normals.release(); ctx->texcoords.release();
+        if (sc->normals && (rc = dev_upload(ctx, ctx->normals, sc->normals, (size_t)n_verts * 12))) return rc;
+        if (sc->tex_coords && (rc = dev_upload(ctx, ctx->texcoords, sc->tex_coords, (size_t)n_verts * 8))) return rc;
+
+        SceneDev &s = ctx->sdev;
+        s.nodes = (const WideNode *)ctx->nodes.p;
+        s.tris = (const TriRecord *)ctx->tris.p;
+        s.big = (const BigLeaf *)ctx->big.p;
+        s.tri_idx = (const RefTriangle *)ctx->tri_idx.p;
+        s.normals = (const float *)ctx->normals.p;
+        s.texcoords = (const float *)ctx->texcoords.p;
+        for (int k = 0; k < 2; k++) {
+            s.tex[k] = (const uint32_t *)(ctx->tex[k].p ? ctx->tex[k].p : ctx->white.p);
+            s.tex_w[k] = ctx->tex[k].p ? ctx->tex_w[k] : 1;
+            s.tex_h[k] = ctx->tex[k].p ? ctx->tex_h[k] : 1;
+        }
+        for (int k = 0; k < 6; k++) s.root_box[k] = nodes[0].bounds[k];
+        s.root_ref = root_ref;
+
+        ctx->info.node_count = n_nodes; ctx->info.triangle_count = n_tris; ctx->info.vertex_count = n_verts;
+        ctx->info.inner_node_count = n_inner; ctx->info.big_leaf_count = (uint32_t)big.size(); ctx->info.max_depth = max_depth;
+        ctx->info.device_bytes = ctx->nodes.bytes + ctx->tris.bytes + ctx->big.bytes + ctx->tri_idx.bytes + ctx->normals.bytes + ctx->texcoords.bytes;
+        ctx->has_scene = true;
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, RTAMD_ERR_OUT_OF_MEMORY, "out of host memory while converting the scene");
+    }
+    return RTAMD_OK;
+}
+
+int rtamd_upload_texture(rtamd_context *ctx, uint32_t slot, const uint8_t *rgb8, uint32_t width, uint32_t height) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (slot > 1) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "texture slot %u: the shader has modelTextures[2]", slot);
+    if (!rgb8 || width == 0 || height == 0 || width > 32768 || height > 32768) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "bad texture %ux%u", width, height);
+    int rc = ensure_ctx_device(ctx);
+    if (rc) return rc;
+    try {
+        // GL_RGB / UNSIGNED_BYTE rows with the default GL_UNPACK_ALIGNMENT of 4
+        // (texture.rs:14-24 never changes it) into RGBA8.
+        const size_t row_stride = ((size_t)width * 3 + 3) & ~(size_t)3;
+        const bool tight = row_stride == (size_t)width * 3;
+        std::vector<uint32_t> rgba((size_t)width * height);
+        for (uint32_t y = 0; y < height; y++) {
+            // A caller that hands over tightly packed rows whose length is not a
+            // multiple of 4 would be mis-read by GL; we take the rows as tightly
+            // packed (what the caller means) and document the difference.
+            const uint8_t *row = rgb8 + (size_t)y * (size_t)width * 3;
+            (void)tight;
+            for (uint32_t x = 0; x < width; x++)
+                rgba[(size_t)y * width + x] = (uint32_t)row[3 * x] | ((uint32_t)row[3 * x + 1] << 8) | ((uint32_t)row[3 * x + 2] << 16) | 0xFF000000u;
+        }
+        if ((rc = dev_upload(ctx, ctx->tex[slot], rgba.data(), rgba.size() * 4))) return rc;
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, RTAMD_ERR_OUT_OF_MEMORY, "out of host memory");
+    }
+    ctx->tex_w[slot] = (int32_t)width; ctx->tex_h[slot] = (int32_t)height;
+    ctx->sdev.tex[slot] = (const uint32_t *)ctx->tex[slot].p;
+    ctx->sdev.tex_w[slot] = (int32_t)width; ctx->sdev.tex_h[slot] = (int32_t)height;
+    return RTAMD_OK;
+}
+
+int rtamd_render_device(rtamd_context *ctx, const rtamd_frame_desc *desc, const rtamd_frame_out *out) {
+    int rc = check_frame(ctx, desc, out);
+    if (rc) return rc;
+    if ((rc = ensure_ctx_device(ctx))) return rc;
+    JobParams p;
+    fill_job(ctx, desc, out, p);
+    return launch_main(ctx, MODE_FUSED, out->counts != nullptr, p);
+}
+
+int rtamd_render(rtamd_context *ctx, const rtamd_frame_desc *desc, const rtamd_frame_out *out) {
+    int rc = check_frame(ctx, desc, out);
+    if (rc) return rc;
+    if ((rc = ensure_ctx_device(ctx))) return rc;
+    const size_t n_px = (size_t)desc->width * desc->height;
+    uint32_t n_tiles = n_tiles_of(desc->width, desc->height, nullptr);
+    const size_t n_out = desc->tile_world == 1 ? n_px : (size_t)local_tiles(n_tiles, desc->tile_rank, desc->tile_world) * RTAMD_TILE_PIXELS;
+    DevBuf d_dir, d_org, d_rgba, d_id, d_t, d_cnt;
+    auto cleanup = [&]() { d_dir.release(); d_org.release(); d_rgba.release(); d_id.release(); d_t.release(); d_cnt.release(); };
+    rtamd_frame_desc dd = *desc;
+    rtamd_frame_out od{};
+    rc = RTAMD_OK;
+    do {
+        if (desc->dir) {
+            if ((rc = dev_upload(ctx, d_dir, desc->dir, n_px * 12))) break;
+            if ((rc = dev_upload(ctx, d_org, desc->org, n_px * 12))) break;
+            dd.dir = (const float *)d_dir.p; dd.org = (const float *)d_org.p;
+        }
+        if (out->rgba32f) { if ((rc = dev_alloc(ctx, d_rgba, n_out * 16))) break; od.rgba32f = (float *)d_rgba.p; }
+        if (out->hit_id) { if ((rc = dev_alloc(ctx, d_id, n_out * 4))) break; od.hit_id = (uint32_t *)d_id.p; }
+        if (out->hit_t) { if ((rc = dev_alloc(ctx, d_t, n_out * 4))) break; od.hit_t = (float *)d_t.p; }
+        if (out->counts) { if ((rc = dev_alloc(ctx, d_cnt, n_out * 8))) break; od.counts = (uint32_t *)d_cnt.p; }
+        // pixels of partial edge tiles that fall outside the frame are never written: define them as 0
+        if (desc->tile_world != 1) {
+            hipError_t e = hipSuccess;
+            if (od.rgba32f) e = hipMemsetAsync(od.rgba32f, 0, n_out * 16, ctx->stream);
+            if (e == hipSuccess && od.hit_id) e = hipMemsetAsync(od.hit_id, 0, n_out * 4, ctx->stream);
+            if (e == hipSuccess && od.hit_t) e = hipMemsetAsync(od.hit_t, 0, n_out * 4, ctx->stream);
+            if (e == hipSuccess && od.counts) e = hipMemsetAsync(od.counts, 0, n_out * 8, ctx->stream);
+            if (e != hipSuccess) { rc = fail(ctx, RTAMD_ERR_DEVICE, "hipMemsetAsync failed: %s", hipGetErrorString(e)); break; }
+        }
+        if ((rc = rtamd_render_device(ctx, &dd, &od))) break;
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { rc = fail(ctx, RTAMD_ERR_DEVICE, "render kernel failed: %s", hipGetErrorString(e)); break; }
+        if (out->rgba32f && (e = hipMemcpy(out->rgba32f, od.rgba32f, n_out * 16, hipMemcpyDeviceToHost)) != hipSuccess) { rc = fail(ctx, RTAMD_ERR_DEVICE, "copy-back failed: %s", hipGetErrorString(e)); break; }
+        if (out->hit_id && (e = hipMemcpy(out->hit_id, od.hit_id, n_out * 4, hipMemcpyDeviceToHost)) != hipSuccess) { rc = fail(ctx, RTAMD_ERR_DEVICE, "copy-back failed: %s", hipGetErrorString(e)); break; }
+        if (out->hit_t && (e = hipMemcpy(out->hit_t, od.hit_t, n_out * 4, hipMemcpyDeviceToHost)) != hipSuccess) { rc = fail(ctx, RTAMD_ERR_DEVICE, "copy-back failed: %s", hipGetErrorString(e)); break; }
+        if (out->counts && (e = hipMemcpy(out->counts, od.counts, n_out * 8, hipMemcpyDeviceToHost)) != hipSuccess) { rc = fail(ctx, RTAMD_ERR_DEVICE, "copy-back failed: %s", hipGetErrorString(e)); break; }
+    } while (0);
+    cleanup();
+    return rc;
+}
+
+int rtamd_trace_device(rtamd_context *ctx, uint64_t n, const float *org, const float *dir, float *hits) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (!ctx->has_scene) return fail(ctx, RTAMD_ERR_NO_SCENE, "no scene uploaded");
+    if (n == 0) return RTAMD_OK;
+    if (!org || !dir || !hits) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "org / dir / hits is NULL");
+    if (n > 0xFFFFFFFFull) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "at most 2^32-1 rays per call");
+    int rc = ensure_ctx_device(ctx);
+    if (rc) return rc;
+    JobParams p;
+    std::memset(&p, 0, sizeof p);
+    p.dir = dir; p.org = org; p.hits = hits; p.n_rays = n;
+    p.n_items = (uint32_t)((n + 63) / 64);
+    p.world = 1;
+    return launch_main(ctx, MODE_TRACE, false, p);
+}
+
+int rtamd_trace(rtamd_context *ctx, uint64_t n, const float *org, const float *dir, float *hits) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (!ctx->has_scene) return fail(ctx, RTAMD_ERR_NO_SCENE, "no scene uploaded");
+    if (n == 0) return RTAMD_OK;
+    if (!org || !dir || !hits) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "org / dir / hits is NULL");
+    int rc = ensure_ctx_device(ctx);
+    if (rc) return rc;
+    DevBuf d_org, d_dir, d_hits;
+    do {
+        if ((rc = dev_upload(ctx, d_org, org, n * 12))) break;
+        if ((rc = dev_upload(ctx, d_dir, dir, n * 12))) break;
+        if ((rc = dev_alloc(ctx, d_hits, n * 16))) break;
+        if ((rc = rtamd_trace_device(ctx, n, (const float *)d_org.p, (const float *)d_dir.p, (float *)d_hits.p))) break;
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { rc = fail(ctx, RTAMD_ERR_DEVICE, "trace kernel failed: %s", hipGetErrorString(e)); break; }
+        if ((e = hipMemcpy(hits, d_hits.p, n * 16, hipMemcpyDeviceToHost)) != hipSuccess) { rc = fail(ctx, RTAMD_ERR_DEVICE, "copy-back failed: %s", hipGetErrorString(e)); break; }
+    } while (0);
+    d_org.release(); d_dir.release(); d_hits.release();
+    return rc;
+}
+
+int rtamd_generate_rays_device(rtamd_context *ctx, uint32_t width, uint32_t height, const float inv_proj_view[16],
+                               float near_plane, float far_plane, float *dir_out) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (!inv_proj_view || !dir_out || width == 0 || height == 0) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "bad generate_rays arguments");
+    if ((uint64_t)width * height > 0x7FFFFFFFull) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "frame too large");
+    int rc = ensure_ctx_device(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ipv.p, inv_proj_view, 64, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t n = width * height;
+    hipLaunchKernelGGL(k_generate_rays, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const float *)ctx->ipv.p, near_plane, far_plane, width, height, dir_out);
+    HIP_TRY(ctx, hipGetLastError());
+    // inv_proj_view is a host pointer that may die after return: make the copy complete
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RTAMD_OK;
+}
+
+int rtamd_generate_rays(rtamd_context *ctx, uint32_t width, uint32_t height, const float inv_proj_view[16],
+                        float near_plane, float far_plane, float *dir_out) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (!inv_proj_view || !dir_out || width == 0 || height == 0) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "bad generate_rays arguments");
+    int rc = ensure_ctx_device(ctx);
+    if (rc) return rc;
+    DevBuf d;
+    size_t bytes = (size_t)width * height * 12;
+    if ((rc = dev_alloc(ctx, d, bytes))) return rc;
+    rc = rtamd_generate_rays_device(ctx, width, height, inv_proj_view, near_plane, far_plane, (float *)d.p);
+    if (!rc) {
+        hipError_t e = hipMemcpy(dir_out, d.p, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(ctx, RTAMD_ERR_DEVICE, "copy-back failed: %s", hipGetErrorString(e));
+    }
+    d.release();
+    return rc;
+}
+
+uint32_t rtamd_tiles_per_rank(uint32_t width, uint32_t height, uint32_t tile_world) {
+    if (tile_world == 0) return 0;
+    return local_tiles(n_tiles_of(width, height, nullptr), 0, tile_world);
+}
+
+int rtamd_assemble_tiles_device(rtamd_context *ctx, const void *gathered, uint32_t width, uint32_t height,
+                                uint32_t tile_world, uint32_t elems_per_pixel, void *frame_out) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (!gathered || !frame_out || width == 0 || height == 0 || tile_world == 0 || elems_per_pixel == 0 || elems_per_pixel > 4)
+        return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "bad assemble_tiles arguments");
+    int rc = ensure_ctx_device(ctx);
+    if (rc) return rc;
+    uint32_t tiles_x = 0;
+    uint32_t n_tiles = n_tiles_of(width, height, &tiles_x);
+    uint32_t per_rank = local_tiles(n_tiles, 0, tile_world);
+    uint32_t n = width * height;
+    hipLaunchKernelGGL(k_assemble_tiles, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t *)gathered, width, height,
+                       tile_world, tiles_x, per_rank, elems_per_pixel, (uint32_t *)frame_out);
+    HIP_TRY(ctx, hipGetLastError());
+    return RTAMD_OK;
+}
+
+int rtamd_get_scene_info(const rtamd_context *ctx, rtamd_scene_info *info) {
+    if (!ctx || !info) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (!ctx->has_scene) return RTAMD_ERR_NO_SCENE;
+    *info = ctx->info;
+    return RTAMD_OK;
+}
+
+int rtamd_last_kernel_ms(rtamd_context *ctx, float *ms) {
+    if (!ctx || !ms) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (!ctx->ev_valid) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "no kernel has been launched yet");
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
+    return RTAMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,194 @@
+"""HipRayTracer — Python caller of the C-ABI device library (include/rtamd.h).
+
+It plays the role main.rs + gl_wrapper play in the reference (upload the five
+scene slices and two albedo textures, src/main.rs:93-102; dispatch the fused
+pass, ray_trace_and_shade.frag; or the split trace pass, ray_trace.frag) but
+every call goes straight through librtamd.so — there is no Python or CPU compute
+path here, and a missing library or GPU raises.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _ffi
+from .host import FAR, NEAR
+
+NO_HIT = 0xFFFFFFFF
+TILE_DIM = 32
+TILE_PIXELS = TILE_DIM * TILE_DIM
+
+
+class RtamdError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"rtamd error {code}: {message}")
+        self.code = code
+
+
+def _ptr(a):
+    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+class HipRayTracer:
+    def __init__(self, device=0):
+        self._lib = _ffi.device_lib()
+        h = ctypes.c_void_p()
+        rc = self._lib.rtamd_context_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise RtamdError(rc, self._lib.rtamd_last_error(None).decode())
+        self._h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rtamd_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RtamdError(rc, self._lib.rtamd_last_error(self._h).decode())
+
+    # ---- context ----------------------------------------------------------
+    def set_stream(self, hip_stream):
+        self._check(self._lib.rtamd_context_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)))
+
+    def synchronize(self):
+        self._check(self._lib.rtamd_synchronize(self._h))
+
+    def set_kernel_variant(self, variant):
+        self._check(self._lib.rtamd_set_kernel_variant(self._h, int(variant)))
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float()
+        self._check(self._lib.rtamd_last_kernel_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def scene_info(self):
+        info = _ffi.SceneInfo()
+        self._check(self._lib.rtamd_get_scene_info(self._h, ctypes.byref(info)))
+        return info
+
+    # ---- uploads ----------------------------------------------------------
+    def upload_scene(self, scene):
+        """scene: dict(nodes[36 B], triangles[16 B], positions, tex_coords|None, normals|None)."""
+        nodes = np.ascontiguousarray(scene["nodes"])
+        tris = np.ascontiguousarray(scene["triangles"])
+        pos = np.ascontiguousarray(scene["positions"], dtype=np.float32)
+        tc = scene.get("tex_coords")
+        nr = scene.get("normals")
+        tc = None if tc is None else np.ascontiguousarray(tc, dtype=np.float32)
+        nr = None if nr is None else np.ascontiguousarray(nr, dtype=np.float32)
+        if nodes.size and nodes.dtype.itemsize != 36 or tris.size and tris.dtype.itemsize != 16:
+            raise ValueError("nodes must be 36-byte and triangles 16-byte records")
+        d = _ffi.SceneDesc(nodes.ctypes.data if nodes.size else None, len(nodes), tris.ctypes.data if tris.size else None, len(tris),
+                           pos.ctypes.data if pos.size else None, pos.size // 3,
+                           None if tc is None else tc.ctypes.data, None if nr is None else nr.ctypes.data)
+        self._check(self._lib.rtamd_upload_scene(self._h, ctypes.byref(d)))
+
+    def upload_texture(self, slot, rgb8):
+        t = np.ascontiguousarray(rgb8, dtype=np.uint8)
+        if t.ndim != 3 or t.shape[2] != 3:
+            raise ValueError("texture must be (h, w, 3) uint8")
+        self._check(self._lib.rtamd_upload_texture(self._h, int(slot), ctypes.c_void_p(t.ctypes.data), t.shape[1], t.shape[0]))
+
+    # ---- fused render -----------------------------------------------------
+    def _frame_desc(self, width, height, dir_ptr, org_ptr, camera, has_tex_coords, has_normals, tile_rank, tile_world):
+        d = _ffi.FrameDesc()
+        d.width, d.height = int(width), int(height)
+        d.dir, d.org = dir_ptr, org_ptr
+        if camera is not None:
+            inv, pos = camera
+            inv = np.asarray(inv, dtype=np.float32).reshape(16)
+            for i in range(16):
+                d.inv_proj_view[i] = float(inv[i])
+            for i in range(3):
+                d.cam_pos[i] = float(np.float32(pos[i]))
+        d.near_plane, d.far_plane = NEAR, FAR
+        d.has_tex_coords, d.has_normals = int(bool(has_tex_coords)), int(bool(has_normals))
+        d.tile_rank, d.tile_world = int(tile_rank), int(tile_world)
+        return d
+
+    def tiles_per_rank(self, width, height, tile_world):
+        return int(self._lib.rtamd_tiles_per_rank(width, height, tile_world))
+
+    def local_tile_count(self, width, height, tile_rank, tile_world):
+        n = ((width + TILE_DIM - 1) // TILE_DIM) * ((height + TILE_DIM - 1) // TILE_DIM)
+        return (n - tile_rank + tile_world - 1) // tile_world if tile_rank < n else 0
+
+    def render(self, width, height, dir=None, org=None, camera=None, has_tex_coords=False, has_normals=False,
+               tile_rank=0, tile_world=1, want=("rgba", "hit_id", "hit_t")):
+        """Host-buffer render (rtamd_render).  Either dir+org arrays (h*w*3 float32) or
+        camera=(inv_proj_view[16], position[3]) for on-device ray generation.
+        Returns a dict of numpy arrays (flat pixel index; see rtamd_frame_out)."""
+        if dir is not None:
+            dir = np.ascontiguousarray(dir, dtype=np.float32).reshape(-1, 3)
+            org = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
+            if len(dir) != width * height or len(org) != width * height:
+                raise ValueError("dir/org must hold width*height rays")
+        elif camera is None:
+            raise ValueError("give dir+org or camera")
+        n_out = width * height if tile_world == 1 else self.local_tile_count(width, height, tile_rank, tile_world) * TILE_PIXELS
+        res = {}
+        if "rgba" in want:
+            res["rgba"] = np.zeros((n_out, 4), np.float32)
+        if "hit_id" in want:
+            res["hit_id"] = np.zeros(n_out, np.uint32)
+        if "hit_t" in want:
+            res["hit_t"] = np.zeros(n_out, np.float32)
+        if "counts" in want:
+            res["counts"] = np.zeros((n_out, 2), np.uint32)
+        d = self._frame_desc(width, height, _ptr(dir), _ptr(org), camera, has_tex_coords, has_normals, tile_rank, tile_world)
+        o = _ffi.FrameOut(_ptr(res.get("rgba")), _ptr(res.get("hit_id")), _ptr(res.get("hit_t")), _ptr(res.get("counts")))
+        self._check(self._lib.rtamd_render(self._h, ctypes.byref(d), ctypes.byref(o)))
+        return res
+
+    def render_device(self, width, height, dir_ptr=0, org_ptr=0, camera=None, has_tex_coords=False, has_normals=False,
+                      tile_rank=0, tile_world=1, rgba_ptr=0, hit_id_ptr=0, hit_t_ptr=0, counts_ptr=0):
+        """Device-pointer render (rtamd_render_device): integers are raw device addresses
+        (e.g. torch.Tensor.data_ptr()); asynchronous on the context's stream."""
+        d = self._frame_desc(width, height, ctypes.c_void_p(dir_ptr or None) if dir_ptr else None,
+                             ctypes.c_void_p(org_ptr) if org_ptr else None, camera, has_tex_coords, has_normals, tile_rank, tile_world)
+        o = _ffi.FrameOut(rgba_ptr or None, hit_id_ptr or None, hit_t_ptr or None, counts_ptr or None)
+        self._check(self._lib.rtamd_render_device(self._h, ctypes.byref(d), ctypes.byref(o)))
+
+    # ---- split-pipeline trace --------------------------------------------
+    def trace(self, org, dir):
+        org = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
+        dir = np.ascontiguousarray(dir, dtype=np.float32).reshape(-1, 3)
+        if len(org) != len(dir):
+            raise ValueError("org and dir must have the same length")
+        hits = np.zeros((len(dir), 4), np.float32)
+        self._check(self._lib.rtamd_trace(self._h, len(dir), _ptr(org), _ptr(dir), _ptr(hits)))
+        return hits
+
+    def trace_device(self, n, org_ptr, dir_ptr, hits_ptr):
+        self._check(self._lib.rtamd_trace_device(self._h, int(n), ctypes.c_void_p(org_ptr), ctypes.c_void_p(dir_ptr), ctypes.c_void_p(hits_ptr)))
+
+    # ---- ray generation / assembly -----------------------------------------
+    def generate_rays(self, width, height, inv_proj_view):
+        inv = np.ascontiguousarray(inv_proj_view, dtype=np.float32).reshape(16)
+        out = np.zeros((height, width, 3), np.float32)
+        self._check(self._lib.rtamd_generate_rays(self._h, width, height, inv.ctypes.data_as(_ffi.c_float_p), NEAR, FAR, _ptr(out)))
+        return out
+
+    def assemble_tiles_device(self, gathered_ptr, width, height, tile_world, elems_per_pixel, frame_ptr):
+        self._check(self._lib.rtamd_assemble_tiles_device(self._h, ctypes.c_void_p(gathered_ptr), width, height, tile_world,
+                                                          elems_per_pixel, ctypes.c_void_p(frame_ptr)))
+
+
+def assemble_tiles_host(blocks, width, height, tile_world, elems):
+    """Pure-numpy statement of the tile layout (used by CPU tests of the sharding
+    logic): blocks[r] is rank r's compact tile-major array (n_local*1024, elems)."""
+    tiles_x = (width + TILE_DIM - 1) // TILE_DIM
+    out = np.zeros((height, width, elems), dtype=blocks[0].dtype)
+    ys, xs = np.mgrid[0:height, 0:width]
+    g = (ys // TILE_DIM) * tiles_x + xs // TILE_DIM
+    r = g % tile_world
+    j = g // tile_world
+    off = j * TILE_PIXELS + (ys % TILE_DIM) * TILE_DIM + xs % TILE_DIM
+    for rank in range(tile_world):
+        m = r == rank
+        out[m] = np.asarray(blocks[rank]).reshape(-1, elems)[off[m]]
+    return out

@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ — BUILD CONTAINER ONLY.
+
+Runs the UNMODIFIED reference shaders (read from /root/reference/res/shaders at
+run time, never copied) on Mesa llvmpipe through oracle/glsl_ref.c and stores
+inputs + outputs as compressed .npz files:
+
+  inputs   nodes / triangles / positions / tex_coords / normals  (the five SSBO
+           slices, built from the reference's res/models/*.obj by the host layer),
+           dir / org ray arrays (h, w, 3; row 0 = bottom), tex0 / tex1 RGB8
+  outputs  b_trace  (h, w, 4)  ray_trace/ray_trace.frag   -> (t, u, v, bits(idx))
+           b_fused  (h, w, 4)  ray_trace_and_shade.frag   -> fragCol
+           b_trace_rand (n, 1, 4) same shader on incoherent rays (secondary-ray stand-in)
+
+The fixtures are data only.  Usage:  python tests/golden/make_golden.py
+"""
+import math
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+from oracles import OracleB  # noqa: E402
+from raytracer_amd import host  # noqa: E402
+
+REF = "/root/reference/res"
+W, H = 160, 120
+
+
+def load_rgb(path):
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGB")).copy()
+
+
+def camera_for(pos, dist, offset=(1.0, 0.4, 0.6), fov_deg=120.0):
+    lo, hi = pos.min(0), pos.max(0)
+    c = (lo + hi) / 2
+    r = np.linalg.norm(hi - lo) / 2
+    off = np.asarray(offset, np.float64)
+    eye = c + dist * r * off / np.linalg.norm(off)
+    d = c - eye
+    d /= np.linalg.norm(d)
+    return host.Camera(W / H, fov=math.radians(fov_deg), position=eye.astype(np.float32), direction=d.astype(np.float32))
+
+
+def random_rays(pos, n, seed):
+    rng = np.random.default_rng(seed)
+    lo, hi = pos.min(0), pos.max(0)
+    c, e = (lo + hi) / 2, (hi - lo)
+    org = (c + rng.uniform(-1.0, 1.0, (n, 3)) * e).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d.astype(np.float32)
+    d[::97] = 0.0  # NO_RAY pixels (ray_trace.frag:6,133)
+    return org.reshape(n, 1, 3), d.reshape(n, 1, 3)
+
+
+def main():
+    B = OracleB()
+    print("oracle B:", B.renderer)
+    cases = [
+        # name, obj, camera distance (in bbox radii), textures
+        ("cube", "cube.obj", 1.6, None),
+        ("f16", "f16.obj", 0.55, ("F16s.bmp", "F16t.bmp")),
+        ("teapot", "teapot.obj", 0.8, None),
+        ("bunny", "bunny.obj", 0.7, None),
+    ]
+    for name, obj, dist, texs in cases:
+        model = host.ResourceParser.parse_model(open(os.path.join(REF, "models", obj)).read())
+        model.build_bvh()
+        sc = model.scene_arrays()
+        cam = camera_for(sc["positions"], dist)
+        dirs, orgs = cam.primary_rays(W, H)
+        tex0 = tex1 = None
+        if texs:
+            tex0, tex1 = (load_rgb(os.path.join(REF, "textures", t)) for t in texs)
+        b_trace, _ = B.trace(sc, dirs, orgs)
+        b_fused, _ = B.fused(sc, dirs, orgs, model.has_tex_coords(), model.has_normals(), tex0, tex1)
+        ro, rd = random_rays(sc["positions"], 4096, seed=1234)
+        b_rand, _ = B.trace(sc, rd, ro)
+        out = {
+            "nodes": sc["nodes"], "triangles": sc["triangles"], "positions": sc["positions"],
+            "dir": dirs, "org": orgs, "rand_dir": rd, "rand_org": ro,
+            "has_tex_coords": np.uint8(model.has_tex_coords()), "has_normals": np.uint8(model.has_normals()),
+            "b_trace": b_trace, "b_fused": b_fused, "b_trace_rand": b_rand,
+            "renderer": np.array(B.renderer),
+        }
+        if sc["tex_coords"] is not None:
+            out["tex_coords"] = sc["tex_coords"]
+        if sc["normals"] is not None:
+            out["normals"] = sc["normals"]
+        if tex0 is not None:
+            out["tex0"], out["tex1"] = tex0, tex1
+        path = os.path.join(HERE, f"golden_{name}.npz")
+        np.savez_compressed(path, **out)
+        hits = int((b_trace[..., 0] < 1e30).sum())
+        print(f"{name}: {len(sc['triangles'])} tris, {len(sc['nodes'])} nodes, {hits}/{W * H} hit pixels, "
+              f"{int((b_rand[..., 0] < 1e30).sum())}/4096 random hits -> {os.path.getsize(path) / 1e6:.2f} MB")
+
+    # special values: axis-parallel rays (1/0 = inf, 0*inf = NaN in the slab test),
+    # origins on box planes, denormal coordinates (llvmpipe runs FTZ/DAZ)
+    pos = np.array([[0, 0, 0], [2, 0, 0], [0, 2, 0]], np.float32)
+    tri = np.array([[0, 1, 2, 0]], np.uint32).view(host.TRIANGLE_DTYPE).reshape(-1)
+    nodes = np.zeros(1, host.NODE_DTYPE)
+    nodes["bounds"][0] = [0, 0, 0, 1, 2, 0]
+    nodes["is_leaf"] = 1
+    nodes["b"] = 1
+    sc = {"nodes": nodes, "triangles": tri, "positions": pos, "tex_coords": None, "normals": None}
+    hh = ww = 8
+    orgs = np.zeros((hh, ww, 3), np.float32)
+    dirs = np.zeros((hh, ww, 3), np.float32)
+    orgs[..., 0] = np.array([0, 1, 0.5, 1, 0, 1, 0, 0.5], np.float32)[None, :]
+    dirs[..., 0] = np.array([0, 0, 0, -0.0, -0.0, 1e-30, 1e-30, -0.0], np.float32)[None, :]
+    orgs[..., 1] = np.array([0.25, 0, 2, 0.25, 1e-40, -1e-40, 0.25, 0.25], np.float32)[:, None]
+    orgs[..., 2] = 1
+    dirs[..., 2] = -1
+    orgs[6, :, 0] = np.array([-1e-40, -1e-39, -1e-38, -2e-38, 1e-40, 0, -0.0, 1e-45], np.float32)
+    b_trace, _ = B.trace(sc, dirs, orgs)
+    np.savez_compressed(os.path.join(HERE, "golden_special.npz"), nodes=nodes, triangles=tri, positions=pos, dir=dirs, org=orgs,
+                        b_trace=b_trace, renderer=np.array(B.renderer))
+    print("special:", int((b_trace[..., 0] < 1e30).sum()), "hits of", hh * ww)
+
+
+if __name__ == "__main__":
+    main()

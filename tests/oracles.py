@@ -1,0 +1,172 @@
+"""ctypes wrappers for the two oracles (test infrastructure only).
+
+OracleA  oracle/_build/liboracle_a.so  CPU restatement (oracle/oracle_a.c)
+OracleB  oracle/_ref/libglslref.so     llvmpipe executing the unmodified reference
+                                       shaders (oracle/glsl_ref.c); only usable in
+                                       the build container (needs /root/reference
+                                       and Mesa) — used to generate tests/golden/.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_A_PATH = os.path.join(REPO, "oracle", "_build", "liboracle_a.so")
+ORACLE_B_PATH = os.path.join(REPO, "oracle", "_ref", "libglslref.so")
+REFERENCE_SHADERS = "/root/reference/res/shaders"
+
+
+class _Scene(ctypes.Structure):
+    _fields_ = [("nodes", ctypes.c_void_p), ("n_nodes", ctypes.c_uint32),
+                ("triangles", ctypes.c_void_p), ("n_triangles", ctypes.c_uint32),
+                ("positions", ctypes.c_void_p), ("n_vertices", ctypes.c_uint32),
+                ("texcoords", ctypes.c_void_p), ("normals", ctypes.c_void_p)]
+
+
+def _scene_struct(scene, keep):
+    """scene: dict with nodes/triangles/positions/tex_coords/normals numpy arrays."""
+    nodes = np.ascontiguousarray(scene["nodes"])
+    tris = np.ascontiguousarray(scene["triangles"])
+    pos = np.ascontiguousarray(scene["positions"], dtype=np.float32)
+    tc = scene.get("tex_coords")
+    nr = scene.get("normals")
+    tc = None if tc is None else np.ascontiguousarray(tc, dtype=np.float32)
+    nr = None if nr is None else np.ascontiguousarray(nr, dtype=np.float32)
+    keep.extend([nodes, tris, pos, tc, nr])
+    assert nodes.dtype.itemsize == 36 and tris.dtype.itemsize == 16
+    return _Scene(nodes.ctypes.data, len(nodes), tris.ctypes.data, len(tris), pos.ctypes.data, pos.size // 3,
+                  None if tc is None else tc.ctypes.data, None if nr is None else nr.ctypes.data)
+
+
+WHITE_TEX = np.full((1, 1, 3), 255, np.uint8)
+
+
+def _tex(t):
+    t = WHITE_TEX if t is None else np.ascontiguousarray(t, dtype=np.uint8)
+    assert t.ndim == 3 and t.shape[2] == 3
+    return t
+
+
+def build_oracle_a():
+    subprocess.run(["make", "-s", "-C", os.path.join(REPO, "oracle"), "all"], check=True)
+
+
+class OracleA:
+    def __init__(self):
+        if not os.path.exists(ORACLE_A_PATH):
+            build_oracle_a()
+        L = ctypes.CDLL(ORACLE_A_PATH)
+        vp = ctypes.c_void_p
+        L.oa_render.argtypes = [ctypes.POINTER(_Scene), ctypes.c_uint64, vp, vp, ctypes.c_int, ctypes.c_int,
+                                vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int,
+                                vp, vp, vp, vp, vp, ctypes.c_int]
+        L.oa_render.restype = ctypes.c_int
+        L.oa_trace.argtypes = [ctypes.POINTER(_Scene), ctypes.c_uint64, vp, vp, vp, vp, ctypes.c_int]
+        L.oa_trace.restype = ctypes.c_int
+        L.oa_raycreate.argtypes = [ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_float, ctypes.c_float, vp]
+        L.oa_raycreate.restype = None
+        L.oa_set_flush_denormals.argtypes = [ctypes.c_int]
+        self.L = L
+
+    def set_flush_denormals(self, on):
+        self.L.oa_set_flush_denormals(int(on))
+
+    def render(self, scene, dir, org, has_tex_coords, has_normals, tex0=None, tex1=None, nthreads=1):
+        """Returns dict(rgba, hit_id, hit_t, counts, shadow, overflow) for n = dir.size/3 pixels."""
+        keep = []
+        sc = _scene_struct(scene, keep)
+        d = np.ascontiguousarray(dir, dtype=np.float32).reshape(-1, 3)
+        o = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
+        n = len(d)
+        t0, t1 = _tex(tex0), _tex(tex1)
+        rgba = np.zeros((n, 4), np.float32)
+        hit_id = np.zeros(n, np.uint32)
+        hit_t = np.zeros(n, np.float32)
+        counts = np.zeros((n, 2), np.uint32)
+        shadow = np.zeros(n, np.int8)
+        rc = self.L.oa_render(ctypes.byref(sc), n, d.ctypes.data, o.ctypes.data, int(has_tex_coords), int(has_normals),
+                              t0.ctypes.data, t0.shape[1], t0.shape[0], t1.ctypes.data, t1.shape[1], t1.shape[0],
+                              rgba.ctypes.data, hit_id.ctypes.data, hit_t.ctypes.data, counts.ctypes.data,
+                              shadow.ctypes.data, nthreads)
+        return {"rgba": rgba, "hit_id": hit_id, "hit_t": hit_t, "counts": counts, "shadow": shadow, "overflow": rc != 0}
+
+    def trace(self, scene, org, dir, nthreads=1):
+        keep = []
+        sc = _scene_struct(scene, keep)
+        d = np.ascontiguousarray(dir, dtype=np.float32).reshape(-1, 3)
+        o = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
+        n = len(d)
+        hits = np.zeros((n, 4), np.float32)
+        counts = np.zeros((n, 2), np.uint32)
+        rc = self.L.oa_trace(ctypes.byref(sc), n, o.ctypes.data, d.ctypes.data, hits.ctypes.data, counts.ctypes.data, nthreads)
+        return {"hits": hits, "counts": counts, "overflow": rc != 0}
+
+    def raycreate(self, width, height, inv_proj_view, near, far):
+        m = np.ascontiguousarray(inv_proj_view, dtype=np.float32).reshape(16)
+        out = np.zeros((height, width, 3), np.float32)
+        self.L.oa_raycreate(width, height, m.ctypes.data, near, far, out.ctypes.data)
+        return out
+
+
+class OracleB:
+    """llvmpipe; arrays are (h, w, c) with row 0 = bottom row (GL convention)."""
+
+    def __init__(self, shader_root=REFERENCE_SHADERS):
+        if not os.path.isdir(shader_root):
+            raise RuntimeError(f"reference shaders not found at {shader_root}")
+        if not os.path.exists(ORACLE_B_PATH):
+            subprocess.run(["make", "-s", "-C", os.path.join(REPO, "oracle"), "ref"], check=True)
+        L = ctypes.CDLL(ORACLE_B_PATH)
+        L.glslref_last_error.restype = ctypes.c_char_p
+        L.glslref_renderer.restype = ctypes.c_char_p
+        vp = ctypes.c_void_p
+        L.glslref_init.argtypes = [ctypes.c_char_p]
+        L.glslref_run_fused.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(_Scene), vp, vp, ctypes.c_int, ctypes.c_int,
+                                        vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp,
+                                        ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        L.glslref_run_trace.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(_Scene), vp, vp, vp,
+                                        ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        L.glslref_run_raycreate.argtypes = [ctypes.c_int, ctypes.c_int, vp, ctypes.c_float, ctypes.c_float, vp]
+        if L.glslref_init(shader_root.encode()) != 0:
+            raise RuntimeError("glslref_init: " + L.glslref_last_error().decode())
+        self.L = L
+        self.renderer = L.glslref_renderer().decode()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.L.glslref_last_error().decode())
+
+    def fused(self, scene, dir, org, has_tex_coords, has_normals, tex0=None, tex1=None, warm=0, reps=1):
+        keep = []
+        sc = _scene_struct(scene, keep)
+        d = np.ascontiguousarray(dir, dtype=np.float32)
+        o = np.ascontiguousarray(org, dtype=np.float32)
+        h, w = d.shape[:2]
+        t0, t1 = _tex(tex0), _tex(tex1)
+        out = np.zeros((h, w, 4), np.float32)
+        med = ctypes.c_double()
+        self._check(self.L.glslref_run_fused(w, h, ctypes.byref(sc), d.ctypes.data, o.ctypes.data, int(has_tex_coords),
+                                             int(has_normals), t0.ctypes.data, t0.shape[1], t0.shape[0],
+                                             t1.ctypes.data, t1.shape[1], t1.shape[0], out.ctypes.data, warm, reps,
+                                             ctypes.byref(med)))
+        return out, med.value
+
+    def trace(self, scene, dir, org, warm=0, reps=1):
+        keep = []
+        sc = _scene_struct(scene, keep)
+        d = np.ascontiguousarray(dir, dtype=np.float32)
+        o = np.ascontiguousarray(org, dtype=np.float32)
+        h, w = d.shape[:2]
+        out = np.zeros((h, w, 4), np.float32)
+        med = ctypes.c_double()
+        self._check(self.L.glslref_run_trace(w, h, ctypes.byref(sc), d.ctypes.data, o.ctypes.data, out.ctypes.data,
+                                             warm, reps, ctypes.byref(med)))
+        return out, med.value
+
+    def raycreate(self, width, height, inv_proj_view, near, far):
+        m = np.ascontiguousarray(inv_proj_view, dtype=np.float32).reshape(16)
+        out = np.zeros((height, width, 3), np.float32)
+        self._check(self.L.glslref_run_raycreate(width, height, m.ctypes.data, near, far, out.ctypes.data))
+        return out
