@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Mrays/s and ms/frame at 1080p on the
+Sponza-class scene (BASELINE.json configs[2]), 1..N MI355X.
+
+A step is one frame of the fused hot path (ray_trace_and_shade.frag semantics):
+for every pixel one primary closest-hit traversal, for every hit pixel normal /
+uv interpolation, one sun shadow traversal, one bilinear texture fetch and the
+Phong/sky shading, RGBA32F out.  Rays (dir/org, 24 B per pixel), scene and
+textures are resident in HBM before the timed region.  With N > 1 ranks the
+frame is split into interleaved 32x32 tiles (scene replicated), every rank
+renders its tiles, one RCCL gather brings them to rank 0, which assembles the
+scan-line frame — all inside the timed step.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+VALU_PEAK_TOPS = 78.6        # 157.3 TFLOP/s FMA-counted fp32 vector = 78.6 T un-fused op/s
+
+
+def build_workload(name):
+    from raytracer_amd import host, scenes
+    if name == "atrium_1080p":
+        tri, pos, uv, nrm, cam = scenes.atrium()
+        model = host.Model.from_arrays(tri, pos, uv, nrm)
+        w, h = 1920, 1080
+        tex = (scenes.checker_texture(), scenes.noise_texture())
+    elif name == "atrium_small":
+        tri, pos, uv, nrm, cam = scenes.atrium()
+        model = host.Model.from_arrays(tri, pos, uv, nrm)
+        w, h = 480, 270
+        tex = (scenes.checker_texture(256), scenes.noise_texture(128, 64))
+    elif name == "soup_1m_4k":
+        tri, pos, cam = scenes.triangle_soup(1_000_000)
+        model = host.Model.from_arrays(tri, pos)
+        w, h = 3840, 2160
+        tex = (None, None)
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    model.build_bvh()
+    d = np.asarray(cam["direction"], np.float32)
+    d /= np.linalg.norm(d)
+    camera = host.Camera(w / h, fov=math.radians(cam["fov_deg"]), position=cam["position"], direction=d)
+    return model, camera, w, h, tex
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="atrium_1080p")
+    ap.add_argument("--variant", type=int, default=0, help="0 persistent (default), 1 static A/B baseline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd.renderer import TILE_PIXELS, HipRayTracer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    t0 = time.time()
+    model, camera, W, H, tex = build_workload(args.workload)
+    sc = model.scene_arrays()
+    build_s = time.time() - t0
+    has_tc, has_n = model.has_tex_coords(), model.has_normals()
+
+    tracer = HipRayTracer(local_rank)
+    tracer.set_kernel_variant(args.variant)
+    tracer.upload_scene(sc)
+    for slot, t in enumerate(tex):
+        if t is not None:
+            tracer.upload_texture(slot, t)
+    # a non-default stream shared by torch (events, RCCL) and the library's launches
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    tracer.set_stream(stream.cuda_stream)
+
+    # rays resident in HBM (the fused shader's `dir` / `org` textures)
+    n_px = W * H
+    inv = camera.inv_proj_view()
+    d_dir = torch.empty((n_px, 3), dtype=torch.float32, device=dev)
+    tracer.generate_rays_device(W, H, inv, d_dir.data_ptr())
+    d_org = torch.tensor(np.asarray(camera.position, np.float32), device=dev).repeat(n_px, 1).contiguous()
+
+    per_rank_tiles = tracer.tiles_per_rank(W, H, world)
+    n_local_out = n_px if world == 1 else per_rank_tiles * TILE_PIXELS
+    d_rgba = torch.zeros((n_local_out, 4), dtype=torch.float32, device=dev)
+    gathered = None
+    frame = None
+    if world > 1 and rank == 0:
+        gathered = [torch.empty_like(d_rgba) for _ in range(world)]
+        gathered_flat = torch.empty((world * n_local_out, 4), dtype=torch.float32, device=dev)
+        frame = torch.empty((n_px, 4), dtype=torch.float32, device=dev)
+
+    def step():
+        tracer.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=has_tc, has_normals=has_n,
+                             tile_rank=rank, tile_world=world, rgba_ptr=d_rgba.data_ptr())
+        if world > 1:
+            if rank == 0:
+                dist.gather(d_rgba, gather_list=list(gathered_flat.view(world, n_local_out, 4).unbind(0)), dst=0)
+                tracer.assemble_tiles_device(gathered_flat.data_ptr(), W, H, world, 4, frame.data_ptr())
+            else:
+                dist.gather(d_rgba, dst=0)
+
+    # ---- untimed: per-pixel counters of the whole frame (rank-local share) for the roofline
+    d_counts = torch.zeros((n_local_out, 2), dtype=torch.int32, device=dev)
+    d_hit = torch.zeros((n_local_out,), dtype=torch.int32, device=dev)
+    tracer.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=has_tc, has_normals=has_n,
+                         tile_rank=rank, tile_world=world, counts_ptr=d_counts.data_ptr(), hit_id_ptr=d_hit.data_ptr(),
+                         rgba_ptr=d_rgba.data_ptr())
+    torch.cuda.synchronize()
+    local_tiles = tracer.local_tile_count(W, H, rank, world)
+    if world == 1:
+        n_primary = n_px
+        valid = torch.ones((n_px,), dtype=torch.bool, device=dev)
+    else:
+        # compact tile layout: pixels of edge tiles outside the frame are never written and carry no rays
+        valid = (d_counts[: local_tiles * TILE_PIXELS, 0] > 0)
+        n_primary = int(valid.sum().item())
+        valid = torch.cat([valid, torch.zeros(n_local_out - valid.numel(), dtype=torch.bool, device=dev)])
+    hitmask = (d_hit != -1) & valid
+    n_shadow = int(hitmask.sum().item())
+    n_box = int(d_counts[:, 0][valid].to(torch.int64).sum().item())
+    n_tri = int(d_counts[:, 1][valid].to(torch.int64).sum().item())
+    stats = torch.tensor([n_primary, n_shadow, n_box, n_tri], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(stats)
+    n_primary_all, n_shadow_all, n_box_all, n_tri_all = (int(x) for x in stats.tolist())
+    rays_per_frame = n_primary_all + n_shadow_all
+
+    # ---- warmup + timed region
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_start = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    ev_ms = ev0.elapsed_time(ev1)
+    tt = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed, ev_ms = float(tt[0]), float(tt[1])
+
+    # ---- kernel-only duration of the dominant kernel (HIP events inside the library, rank 0)
+    kms = []
+    for _ in range(min(args.steps, 50)):
+        tracer.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=has_tc, has_normals=has_n,
+                             tile_rank=rank, tile_world=world, rgba_ptr=d_rgba.data_ptr())
+        kms.append(tracer.last_kernel_ms())
+    kernel_ms = float(np.mean(kms))
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = rays_per_frame * args.steps / elapsed / 1e6
+
+    # algorithmic bytes / ops of ONE launch on this rank:
+    #   36 B per AABB test + 52 B per triangle test + 24 B ray in per ray + 16 B RGBA32F out per pixel
+    #   + per shaded pixel 3x12 B normals + 3x8 B uvs + 16 B triangle record + 4 texels x 4 B
+    shaded_extra = (36 if has_n else 0) + (24 if has_tc else 0) + 16 + 16
+    alg_bytes = 36 * n_box + 52 * n_tri + 24 * (n_primary + n_shadow) + 16 * n_primary + shaded_extra * n_shadow
+    alg_ops = 25 * n_box + 60 * n_tri + 150 * n_shadow
+    launch_ms = ev_ms / args.steps if world == 1 else kernel_ms
+    achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+    out = {
+        "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: procedural Sponza-class atrium, {len(sc['triangles'])} triangles, "
+                               f"{W}x{H}, 1 spp, primary + sun shadow ray + shading (fused ray_trace_and_shade semantics)",
+                   "rays_per_frame": rays_per_frame, "primary_rays": n_primary_all, "shadow_rays": n_shadow_all,
+                   "parallelism": f"tiles{world}" if world > 1 else "single", "kernel_variant": args.variant,
+                   "bvh_build_s": round(build_s, 2)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "kernel": "k_persistent<fused>" if args.variant == 0 else "k_static<fused>",
+                     "launch_ms": round(launch_ms, 5), "kernel_ms_hip_events": round(kernel_ms, 5),
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "aabb_tests_per_ray": round(n_box / max(1, n_primary + n_shadow), 2),
+                     "tri_tests_per_ray": round(n_tri / max(1, n_primary + n_shadow), 2),
+                     "valu": {"achieved_Tops": round(alg_ops / (launch_ms * 1e-3) / 1e12, 3), "peak_Tops": VALU_PEAK_TOPS,
+                              "frac": round(alg_ops / (launch_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS, 5)}},
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        # oracle A (the CPU restatement) on the same frame, bounded: every 2nd pixel row
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        from oracles import OracleA
+        A = OracleA()
+        cores = min(16, os.cpu_count() or 1)
+        dirs = d_dir.view(H, W, 3)[::2].contiguous().cpu().numpy().reshape(-1, 3)
+        orgs = np.broadcast_to(np.asarray(camera.position, np.float32), dirs.shape).copy()
+        reps = 12
+        tc0 = time.perf_counter()
+        for _ in range(reps):
+            r = A.render(sc, dirs, orgs, has_tc, has_n, tex[0], tex[1], nthreads=cores)
+        cpu_s = time.perf_counter() - tc0
+        cpu_rays = reps * (len(dirs) + int((r["hit_id"] != 0xFFFFFFFF).sum()))
+        out["cpu_baseline"] = {"value": round(cpu_rays / cpu_s / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                               "sample": f"oracle/oracle_a.c, {reps} passes over every 2nd pixel row of the same frame "
+                                         f"({len(dirs)} pixels per pass, {cpu_rays} rays in all, {cpu_s:.1f} s wall on {cores} threads)"}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

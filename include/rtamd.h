@@ -200,6 +200,12 @@ int rtamd_last_kernel_ms(rtamd_context *ctx, float *ms);
  * 1 = one lane per pixel, static 8x8 blocks (A/B baseline). */
 int rtamd_set_kernel_variant(rtamd_context *ctx, int variant);
 
+/* Tuning knobs of the persistent kernel (benchmarks / profiling; results never
+ * change): "dyn_thresh" 1..64 — re-fill idle lanes when fewer than this many lanes
+ * of a wave are still traversing; "num_queues" 1..8 — work queues (8 = one per XCD);
+ * "kernel_variant" as rtamd_set_kernel_variant. */
+int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value);
+
 const char *rtamd_version(void);
 
 #ifdef __cplusplus

@@ -66,6 +66,9 @@ typedef struct { const uint8_t *rgb; int w, h; } oa_texture;
 /* options --------------------------------------------------------------- */
 static int g_flush_denormals = 1;   /* set MXCSR FTZ|DAZ in the worker (llvmpipe rasteriser threads do) */
 void oa_set_flush_denormals(int on) { g_flush_denormals = on; }
+/* deepest shader-stack occupancy seen since the last reset (statistics only; racy max is fine) */
+static volatile uint32_t g_max_stack = 0;
+uint32_t oa_max_stack(int reset) { uint32_t v = g_max_stack; if (reset) g_max_stack = 0; return v; }
 
 static void apply_fp_mode(void) {
     unsigned csr = _mm_getcsr();
@@ -155,7 +158,7 @@ static int oa_traverse(const oa_scene *sc, const oa_ray *ray, float *t, uint32_t
             counts[0] += 2;
             float dist0 = oa_aabb(ray, &sc->nodes[node->a], *t);
             float dist1 = oa_aabb(ray, &sc->nodes[node->b], *t);
-#define OA_PUSH(x) do { if (idx >= OA_NODE_STACK_SIZE) return -1; stack[idx++] = (x); } while (0)
+#define OA_PUSH(x) do { if (idx >= OA_NODE_STACK_SIZE) return -1; stack[idx++] = (x); if (idx > g_max_stack) g_max_stack = idx; } while (0)
             if (dist0 < dist1) {
                 if (dist1 != OA_MISS) OA_PUSH(node->b);
                 if (dist0 != OA_MISS) OA_PUSH(node->a);

@@ -12,7 +12,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 HOST_LIB_PATH = os.path.join(LIB_DIR, "librtamd_host.so")
-DEVICE_LIB_PATH = os.path.join(LIB_DIR, "librtamd.so")
+# RTAMD_DEVICE_LIB selects another build of the same library (kernel A/B experiments, tools/kbench.py)
+DEVICE_LIB_PATH = os.environ.get("RTAMD_DEVICE_LIB") or os.path.join(LIB_DIR, "librtamd.so")
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_u8_p = ctypes.POINTER(ctypes.c_uint8)
@@ -142,6 +143,8 @@ def device_lib():
         L.rtamd_last_kernel_ms.restype = ctypes.c_int
         L.rtamd_set_kernel_variant.argtypes = [vp, ctypes.c_int]
         L.rtamd_set_kernel_variant.restype = ctypes.c_int
+        L.rtamd_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
+        L.rtamd_set_option.restype = ctypes.c_int
         L.rtamd_version.argtypes = []
         L.rtamd_version.restype = ctypes.c_char_p
         _device = L

@@ -73,6 +73,7 @@ struct JobParams {
     uint32_t *queues;             // n_queues counters, 16 dwords apart
     uint32_t n_queues;
     uint32_t dyn_thresh;
+    uint32_t *spill;              // k_persistent: [wave slot][SPILL_STACK_ENTRIES][64] stack overflow area
 };
 
 // ---------------------------------------------------------------------------
@@ -146,15 +147,34 @@ struct Trav {
     uint32_t sp;    // number of deferred references on this lane's stack
 };
 
-__device__ __forceinline__ void stack_push(uint32_t *lds, uint32_t *spill, uint32_t tid, uint32_t &sp, uint32_t v) {
-    if (sp < (uint32_t)LDS_STACK_ENTRIES) lds[sp * BLOCK + tid] = v;
-    else if (sp < (uint32_t)MAX_STACK_ENTRIES) spill[sp - LDS_STACK_ENTRIES] = v;
+// Stack policies.  Entry e of thread tid lives at lds[e*BLOCK + tid] (ds_read/write_b32:
+// bank = tid % 32, conflict-free whatever the depths of the lanes).  Deeper entries
+// spill: StackScratch to a private (scratch) array, StackGlobal to the wave slot's
+// slice of an HBM buffer laid out [entry][lane] so that a spill is one coalesced line.
+struct StackScratch {
+    uint32_t *lds;
+    uint32_t spill[SPILL_STACK_ENTRIES];
+    __device__ __forceinline__ void spill_store(uint32_t e, uint32_t v) { spill[e] = v; }
+    __device__ __forceinline__ uint32_t spill_load(uint32_t e) const { return spill[e]; }
+};
+struct StackGlobal {
+    uint32_t *lds;
+    uint32_t *spill;  // this lane's column: entry e at spill[e * 64]
+    __device__ __forceinline__ void spill_store(uint32_t e, uint32_t v) { spill[e * 64u] = v; }
+    __device__ __forceinline__ uint32_t spill_load(uint32_t e) const { return spill[e * 64u]; }
+};
+
+template <class Stack>
+__device__ __forceinline__ void stack_push(Stack &st, uint32_t tid, uint32_t &sp, uint32_t v) {
+    if (__builtin_expect(sp < (uint32_t)LDS_STACK_ENTRIES, 1)) st.lds[sp * BLOCK + tid] = v;
+    else if (sp < (uint32_t)MAX_STACK_ENTRIES) st.spill_store(sp - LDS_STACK_ENTRIES, v);
     sp++;
 }
-__device__ __forceinline__ uint32_t stack_pop(const uint32_t *lds, const uint32_t *spill, uint32_t tid, uint32_t &sp) {
+template <class Stack>
+__device__ __forceinline__ uint32_t stack_pop(const Stack &st, uint32_t tid, uint32_t &sp) {
     sp--;
-    if (sp < (uint32_t)LDS_STACK_ENTRIES) return lds[sp * BLOCK + tid];
-    if (sp < (uint32_t)MAX_STACK_ENTRIES) return spill[sp - LDS_STACK_ENTRIES];
+    if (__builtin_expect(sp < (uint32_t)LDS_STACK_ENTRIES, 1)) return st.lds[sp * BLOCK + tid];
+    if (sp < (uint32_t)MAX_STACK_ENTRIES) return st.spill_load(sp - LDS_STACK_ENTRIES);
     return REF_NONE;
 }
 
@@ -167,33 +187,45 @@ __device__ __forceinline__ void trav_begin(const SceneDev &s, Trav &tr, float t0
     tr.cur = (d == MISS) ? REF_NONE : s.root_ref;
 }
 
+// Slab test of intersectAABB (:53-61) split into its interval and its accept
+// predicate `tmax >= tmin && tmin < t && tmax > 0`; the shader's "return MISS"
+// encoding of a rejected box is only ever compared (!= 1e30, dist0 < dist1), which
+// trav_inner evaluates on the predicates directly.
+__device__ __forceinline__ bool slab(const Ray &r, float minx, float miny, float minz, float maxx, float maxy, float maxz, float t, float &tmin) {
+    float tx1 = (minx - r.ox) * r.rx, tx2 = (maxx - r.ox) * r.rx;
+    float lo = fminf(tx1, tx2), hi = fmaxf(tx1, tx2);
+    float ty1 = (miny - r.oy) * r.ry, ty2 = (maxy - r.oy) * r.ry;
+    lo = fmaxf(lo, fminf(ty1, ty2)); hi = fminf(hi, fmaxf(ty1, ty2));
+    float tz1 = (minz - r.oz) * r.rz, tz2 = (maxz - r.oz) * r.rz;
+    lo = fmaxf(lo, fminf(tz1, tz2)); hi = fminf(hi, fmaxf(tz1, tz2));
+    tmin = lo;
+    return hi >= lo && lo < t && hi > 0.0f;
+}
+
 // One inner-node visit (:138-148): test both children with the current t, descend
-// into the nearer hit child, defer the other.  Equal distances: child b first.
-template <bool COUNT>
-__device__ __forceinline__ void trav_inner(const SceneDev &s, Trav &tr, uint32_t *lds, uint32_t *spill, uint32_t tid, uint32_t &nbox) {
+// into the nearer hit child, defer the other.  With dist = hit ? tmin : 1e30 the
+// shader's `dist0 < dist1` is  hit0 && (!hit1 || tmin0 < tmin1)  (a hit has
+// tmin < t <= 1e30), so equal distances visit child b first, exactly as :142-148.
+template <bool COUNT, class Stack>
+__device__ __forceinline__ void trav_inner(const SceneDev &s, Trav &tr, Stack &st, uint32_t tid, uint32_t &nbox) {
     const float4 *np = reinterpret_cast<const float4 *>(&s.nodes[tr.cur]);
     const float4 q0 = np[0], q1 = np[1], q2 = np[2];
     const uint2 refs = *reinterpret_cast<const uint2 *>(&np[3]);
     if (COUNT) nbox += 2;
-    float dist0 = aabb_dist(tr.ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tr.t);
-    float dist1 = aabb_dist(tr.ray, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr.t);
-    bool hit0 = dist0 != MISS, hit1 = dist1 != MISS;
-    bool a_first = dist0 < dist1;
-    uint32_t first = a_first ? refs.x : refs.y, second = a_first ? refs.y : refs.x;
-    bool hit_first = a_first ? hit0 : hit1, hit_second = a_first ? hit1 : hit0;
-    if (hit_first) {
-        tr.cur = first;
-        if (hit_second) stack_push(lds, spill, tid, tr.sp, second);
-    } else if (hit_second) {
-        tr.cur = second;
-    } else {
-        tr.cur = tr.sp ? stack_pop(lds, spill, tid, tr.sp) : REF_NONE;
-    }
+    float tmin0, tmin1;
+    const bool hit0 = slab(tr.ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tr.t, tmin0);
+    const bool hit1 = slab(tr.ray, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr.t, tmin1);
+    const bool a_first = hit0 && (!hit1 || tmin0 < tmin1);
+    const uint32_t near_ref = a_first ? refs.x : refs.y;
+    const uint32_t far_ref = a_first ? refs.y : refs.x;
+    if (hit0 && hit1) stack_push(st, tid, tr.sp, far_ref);
+    if (hit0 || hit1) tr.cur = near_ref;
+    else tr.cur = tr.sp ? stack_pop(st, tid, tr.sp) : REF_NONE;
 }
 
 // One leaf visit (:122-136): all triangles in ascending order, then pop.
-template <bool COUNT>
-__device__ __forceinline__ void trav_leaf(const SceneDev &s, Trav &tr, const uint32_t *lds, const uint32_t *spill, uint32_t tid, uint32_t &ntri) {
+template <bool COUNT, class Stack>
+__device__ __forceinline__ void trav_leaf(const SceneDev &s, Trav &tr, const Stack &st, uint32_t tid, uint32_t &ntri) {
     uint32_t ref = tr.cur;
     uint32_t count = (ref >> REF_COUNT_SHIFT) & 15u;
     uint32_t first = ref & REF_FIRST_MASK;
@@ -203,17 +235,17 @@ __device__ __forceinline__ void trav_leaf(const SceneDev &s, Trav &tr, const uin
     }
     if (COUNT) ntri += count;
     for (uint32_t i = first; i < first + count; i++) tri_test(tr.ray, s.tris, i, tr.t, tr.idx, tr.u, tr.v);
-    tr.cur = tr.sp ? stack_pop(lds, spill, tid, tr.sp) : REF_NONE;
+    tr.cur = tr.sp ? stack_pop(st, tid, tr.sp) : REF_NONE;
 }
 
 __device__ __forceinline__ bool ref_is_inner(uint32_t ref) { return (ref & REF_LEAF_BIT) == 0 && ref != REF_NONE; }
 
 // Run this lane's traversal to completion (static kernel).
-template <bool COUNT>
-__device__ __forceinline__ void trav_run(const SceneDev &s, Trav &tr, uint32_t *lds, uint32_t *spill, uint32_t tid, uint32_t &nbox, uint32_t &ntri) {
+template <bool COUNT, class Stack>
+__device__ __forceinline__ void trav_run(const SceneDev &s, Trav &tr, Stack &st, uint32_t tid, uint32_t &nbox, uint32_t &ntri) {
     while (tr.cur != REF_NONE) {
-        while (ref_is_inner(tr.cur)) trav_inner<COUNT>(s, tr, lds, spill, tid, nbox);
-        if (tr.cur != REF_NONE) trav_leaf<COUNT>(s, tr, lds, spill, tid, ntri);
+        while (ref_is_inner(tr.cur)) trav_inner<COUNT>(s, tr, st, tid, nbox);
+        if (tr.cur != REF_NONE) trav_leaf<COUNT>(s, tr, st, tid, ntri);
     }
 }
 
@@ -231,7 +263,11 @@ __device__ __forceinline__ V3 sun_dir() {
 __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 // pow(x,y) is undefined in GLSL for x < 0; the pinned reference yields NaN which the
 // following clamp turns into 0 — restated as "negative base => 0".
-__device__ __forceinline__ float pow_clamp01(float x, float y) { return (x >= 0.0f) ? clamp01(powf(x, y)) : 0.0f; }
+// Only the colour (tolerance 1/255) depends on it, so pow is exp2(y*log2(x)) on the
+// hardware transcendental units (v_log_f32 / v_exp_f32, ~1 ulp each).
+__device__ __forceinline__ float pow_clamp01(float x, float y) {
+    return (x >= 0.0f) ? clamp01(__builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x))) : 0.0f;
+}
 
 __device__ __forceinline__ V3 skybox(float dx, float dy, float dz) {
     const V3 sd = sun_dir();
@@ -387,8 +423,10 @@ enum : int { MODE_FUSED = 0, MODE_TRACE = 1 };
 template <int MODE, bool COUNT>
 __global__ void __launch_bounds__(BLOCK) k_persistent(const SceneDev s, const JobParams p) {
     __shared__ uint32_t lds_stack[LDS_STACK_ENTRIES * BLOCK];
-    uint32_t spill[SPILL_STACK_ENTRIES];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    StackGlobal st;
+    st.lds = lds_stack;
+    st.spill = p.spill + ((size_t)(blockIdx.x * (BLOCK / 64) + (tid >> 6)) * SPILL_STACK_ENTRIES) * 64u + lane;
 
     // wave-uniform pool of pending pixels / rays: item `pool_item`, lanes [pool_next, 64)
     uint32_t pool_item = 0, pool_next = 64;
@@ -466,8 +504,8 @@ __global__ void __launch_bounds__(BLOCK) k_persistent(const SceneDev s, const Jo
             const bool busy = tr.cur != REF_NONE;
             if ((uint32_t)__popcll(__ballot(busy)) < thresh) break;
             if (busy) {
-                while (ref_is_inner(tr.cur)) trav_inner<COUNT>(s, tr, lds_stack, spill, tid, nbox);
-                if (tr.cur != REF_NONE) trav_leaf<COUNT>(s, tr, lds_stack, spill, tid, ntri);
+                while (ref_is_inner(tr.cur)) trav_inner<COUNT>(s, tr, st, tid, nbox);
+                if (tr.cur != REF_NONE) trav_leaf<COUNT>(s, tr, st, tid, ntri);
             }
         }
 
@@ -514,7 +552,8 @@ __global__ void __launch_bounds__(BLOCK) k_persistent(const SceneDev s, const Jo
 template <int MODE, bool COUNT>
 __global__ void __launch_bounds__(BLOCK) k_static(const SceneDev s, const JobParams p) {
     __shared__ uint32_t lds_stack[LDS_STACK_ENTRIES * BLOCK];
-    uint32_t spill[SPILL_STACK_ENTRIES];
+    StackScratch st;
+    st.lds = lds_stack;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t item = blockIdx.x * (BLOCK / 64) + (tid >> 6);
     if (item >= p.n_items) return;
@@ -531,7 +570,7 @@ __global__ void __launch_bounds__(BLOCK) k_static(const SceneDev s, const JobPar
         }
         set_ray(tr.ray, o[0], o[1], o[2], d[0], d[1], d[2]);
         trav_begin<COUNT>(s, tr, MISS, nbox);
-        trav_run<COUNT>(s, tr, lds_stack, spill, tid, nbox, ntri);
+        trav_run<COUNT>(s, tr, st, tid, nbox, ntri);
         *reinterpret_cast<float4 *>(p.hits + 4 * ri) = make_float4(tr.t, tr.u, tr.v, __uint_as_float(tr.idx));
         if (COUNT && p.counts) { p.counts[2 * ri] = nbox; p.counts[2 * ri + 1] = ntri; }
         return;
@@ -548,7 +587,7 @@ __global__ void __launch_bounds__(BLOCK) k_static(const SceneDev s, const JobPar
     }
     set_ray(tr.ray, ox, oy, oz, dx, dy, dz);
     trav_begin<COUNT>(s, tr, T_PRIMARY0, nbox);
-    trav_run<COUNT>(s, tr, lds_stack, spill, tid, nbox, ntri);
+    trav_run<COUNT>(s, tr, st, tid, nbox, ntri);
     const float prim_t = tr.t;
     const uint32_t prim_idx = tr.idx;
     V3 c;
@@ -559,7 +598,7 @@ __global__ void __launch_bounds__(BLOCK) k_static(const SceneDev s, const JobPar
         shade_primary(s, p, tr, col_shadow, col_lit, sray);
         tr.ray = sray;
         trav_begin<COUNT>(s, tr, T_PRIMARY0, nbox);
-        trav_run<COUNT>(s, tr, lds_stack, spill, tid, nbox, ntri);
+        trav_run<COUNT>(s, tr, st, tid, nbox, ntri);
         c = (tr.t < T_HIT_LIMIT) ? col_shadow : col_lit;
         id = prim_idx;
     } else {

@@ -62,12 +62,16 @@ constexpr uint32_t REF_INLINE_MAX_COUNT = 15;
 constexpr uint32_t REF_NONE = 0x7FFFFFFFu;  // "no node": an inner index that cannot exist
 constexpr uint32_t MAX_TRIANGLES = 1u << REF_COUNT_SHIFT;
 
-// Traversal stack: LDS_STACK_ENTRIES per lane in LDS, the rest in scratch.  The
+// Traversal stack: LDS_STACK_ENTRIES per lane in LDS, the rest spills (k_static: to
+// scratch; k_persistent: to a per-wave-slot HBM buffer owned by the context).  The
 // reference's shader has 100 entries in all (ray_trace_and_shade.frag:12); upload
 // rejects trees whose deferred-sibling depth exceeds MAX_STACK_ENTRIES.
-constexpr int LDS_STACK_ENTRIES = 12;
-constexpr int SPILL_STACK_ENTRIES = 116;
-constexpr int MAX_STACK_ENTRIES = LDS_STACK_ENTRIES + SPILL_STACK_ENTRIES;
+#ifndef RTAMD_LDS_STACK
+#define RTAMD_LDS_STACK 16
+#endif
+constexpr int LDS_STACK_ENTRIES = RTAMD_LDS_STACK;
+constexpr int MAX_STACK_ENTRIES = 128;
+constexpr int SPILL_STACK_ENTRIES = MAX_STACK_ENTRIES - LDS_STACK_ENTRIES;
 
 constexpr uint32_t RTAMD_TILE_PIXELS = 1024u;  // 32 x 32 (RTAMD_TILE_DIM in include/rtamd.h)
 

@@ -44,6 +44,7 @@ struct rtamd_context {
     int32_t tex_w[2] = {1, 1}, tex_h[2] = {1, 1};
     DevBuf white;
     DevBuf queues;
+    DevBuf spill;  // traversal-stack overflow of the persistent kernel, one slice per resident wave
     DevBuf ipv;  // 16 floats for k_generate_rays
     SceneDev sdev{};
     rtamd_scene_info info{};
@@ -121,6 +122,7 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     p.queues = (uint32_t *)ctx->queues.p;
     p.n_queues = ctx->n_queues;
     p.dyn_thresh = ctx->dyn_thresh;
+    p.spill = (uint32_t *)ctx->spill.p;
     hipStream_t st = ctx->stream;
     const SceneDev &s = ctx->sdev;
     if (ctx->variant == 0) HIP_TRY(ctx, hipMemsetAsync(ctx->queues.p, 0, ctx->queues.bytes, st));
@@ -219,6 +221,12 @@ int rtamd_context_create(int device_ordinal, rtamd_context **out_ctx) {
     if ((rc = query_blocks(ctx, k_persistent<MODE_FUSED, true>, &ctx->persistent_blocks_per_cu[1]))) return bail(rc);
     if ((rc = query_blocks(ctx, k_persistent<MODE_TRACE, false>, &ctx->persistent_blocks_per_cu[2]))) return bail(rc);
     if ((rc = query_blocks(ctx, k_persistent<MODE_TRACE, true>, &ctx->persistent_blocks_per_cu[3]))) return bail(rc);
+    {
+        int max_per_cu = 1;
+        for (int k = 0; k < 4; k++) if (ctx->persistent_blocks_per_cu[k] > max_per_cu) max_per_cu = ctx->persistent_blocks_per_cu[k];
+        size_t waves = (size_t)ctx->num_cu * max_per_cu * (BLOCK / 64);
+        if ((rc = dev_alloc(ctx, ctx->spill, waves * SPILL_STACK_ENTRIES * 64 * sizeof(uint32_t)))) return bail(rc);
+    }
     const uint32_t white = 0xFFFFFFFFu;
     if ((rc = dev_upload(ctx, ctx->white, &white, 4))) return bail(rc);
     if ((rc = dev_alloc(ctx, ctx->queues, 8 * 64))) return bail(rc);
@@ -237,7 +245,7 @@ void rtamd_context_destroy(rtamd_context *ctx) {
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     ctx->nodes.release(); ctx->tris.release(); ctx->big.release(); ctx->tri_idx.release();
     ctx->normals.release(); ctx->texcoords.release(); ctx->tex[0].release(); ctx->tex[1].release();
-    ctx->white.release(); ctx->queues.release(); ctx->ipv.release();
+    ctx->white.release(); ctx->queues.release(); ctx->spill.release(); ctx->ipv.release();
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -264,6 +272,23 @@ int rtamd_set_kernel_variant(rtamd_context *ctx, int variant) {
     if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
     if (variant != 0 && variant != 1) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "unknown kernel variant %d", variant);
     ctx->variant = variant;
+    return RTAMD_OK;
+}
+
+int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (!name) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "option name is NULL");
+    if (!std::strcmp(name, "dyn_thresh")) {
+        if (value < 1 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "dyn_thresh must be 1..64");
+        ctx->dyn_thresh = (uint32_t)value;
+    } else if (!std::strcmp(name, "num_queues")) {
+        if (value < 1 || value > 8) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "num_queues must be 1..8");
+        ctx->n_queues = (uint32_t)value;
+    } else if (!std::strcmp(name, "kernel_variant")) {
+        return rtamd_set_kernel_variant(ctx, (int)value);
+    } else {
+        return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
+    }
     return RTAMD_OK;
 }
 

@@ -60,6 +60,9 @@ class HipRayTracer:
     def set_kernel_variant(self, variant):
         self._check(self._lib.rtamd_set_kernel_variant(self._h, int(variant)))
 
+    def set_option(self, name, value):
+        self._check(self._lib.rtamd_set_option(self._h, name.encode(), int(value)))
+
     def last_kernel_ms(self):
         ms = ctypes.c_float()
         self._check(self._lib.rtamd_last_kernel_ms(self._h, ctypes.byref(ms)))
@@ -172,6 +175,11 @@ class HipRayTracer:
         out = np.zeros((height, width, 3), np.float32)
         self._check(self._lib.rtamd_generate_rays(self._h, width, height, inv.ctypes.data_as(_ffi.c_float_p), NEAR, FAR, _ptr(out)))
         return out
+
+    def generate_rays_device(self, width, height, inv_proj_view, dir_ptr):
+        inv = np.ascontiguousarray(inv_proj_view, dtype=np.float32).reshape(16)
+        self._check(self._lib.rtamd_generate_rays_device(self._h, width, height, inv.ctypes.data_as(_ffi.c_float_p), NEAR, FAR,
+                                                         ctypes.c_void_p(dir_ptr)))
 
     def assemble_tiles_device(self, gathered_ptr, width, height, tile_world, elems_per_pixel, frame_ptr):
         self._check(self._lib.rtamd_assemble_tiles_device(self._h, ctypes.c_void_p(gathered_ptr), width, height, tile_world,

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Kernel A/B bench (GPU box): one workload, many (library build, option) arms,
+interleaved rounds in one process per library, kernel time from HIP events.
+Usage: tools/kbench.py [--workload W] [--rounds N] arm [arm ...]
+  arm = name[:key=value[,key=value...]]   keys: variant, dyn_thresh, num_queues, mode(fused|trace|incoherent)
+Libraries: RTAMD_DEVICE_LIB env (one process = one library)."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="atrium_1080p")
+    ap.add_argument("--rounds", type=int, default=15)
+    ap.add_argument("arms", nargs="+")
+    args = ap.parse_args()
+    import torch
+    import bench
+    from raytracer_amd.renderer import HipRayTracer
+    model, camera, W, H, tex = bench.build_workload(args.workload)
+    sc = model.scene_arrays()
+    dev = torch.device("cuda", 0)
+    tr = HipRayTracer(0)
+    tr.upload_scene(sc)
+    for slot, t in enumerate(tex):
+        if t is not None:
+            tr.upload_texture(slot, t)
+    n = W * H
+    d_dir = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    tr.generate_rays_device(W, H, camera.inv_proj_view(), d_dir.data_ptr())
+    d_org = torch.tensor(np.asarray(camera.position, np.float32), device=dev).repeat(n, 1).contiguous()
+    d_rgba = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+    d_hits = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+    # incoherent rays: shuffled primaries (same ray set, no spatial coherence inside a wave)
+    perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    d_dir_sh = d_dir[perm].contiguous()
+    torch.cuda.synchronize()
+    arms = []
+    for a in args.arms:
+        name, _, kv = a.partition(":")
+        opts = dict(x.split("=") for x in kv.split(",")) if kv else {}
+        arms.append((name, opts))
+    res = {name: [] for name, _ in arms}
+    has_tc, has_n = model.has_tex_coords(), model.has_normals()
+    for r in range(args.rounds + 2):
+        for name, o in arms:
+            tr.set_option("kernel_variant", int(o.get("variant", 0)))
+            tr.set_option("dyn_thresh", int(o.get("dyn_thresh", 40)))
+            tr.set_option("num_queues", int(o.get("num_queues", 8)))
+            mode = o.get("mode", "fused")
+            if mode == "fused":
+                tr.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=has_tc, has_normals=has_n, rgba_ptr=d_rgba.data_ptr())
+            elif mode == "trace":
+                tr.trace_device(n, d_org.data_ptr(), d_dir.data_ptr(), d_hits.data_ptr())
+            else:
+                tr.trace_device(n, d_org.data_ptr(), d_dir_sh.data_ptr(), d_hits.data_ptr())
+            ms = tr.last_kernel_ms()
+            if r >= 2:
+                res[name].append(ms)
+    lib = os.environ.get("RTAMD_DEVICE_LIB", "default")
+    for name, _ in arms:
+        v = np.array(res[name])
+        print(json.dumps({"lib": os.path.basename(lib), "arm": name, "median_ms": round(float(np.median(v)), 4), "min_ms": round(float(v.min()), 4)}))
+
+
+if __name__ == "__main__":
+    main()

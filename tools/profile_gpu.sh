@@ -1,0 +1,22 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): kernel-trace stats + separate PMC passes for
+# one bench variant; raw output under gpurun_out/prof_<tag>/, summary printed by
+# tools/pmc_summary.py.  Usage: tools/profile_gpu.sh <tag> <bench args...>
+set -e -o pipefail
+tag=$1; shift
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+out=gpurun_out/prof_$tag
+rm -rf "$out"; mkdir -p "$out"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline "$@" > "$out/trace.log" 2>&1
+pass() {
+  name=$1; shift
+  timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$out/pmc_$name" -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline $BENCH_ARGS > "$out/pmc_$name.log" 2>&1
+}
+BENCH_ARGS="$*"
+pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE
+pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT
+pass tc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE TCC_EA0_RDREQ_DRAM_sum
+python3 tools/pmc_summary.py "$out" | tee "$out/summary.txt"
