@@ -202,7 +202,9 @@ int rtamd_set_kernel_variant(rtamd_context *ctx, int variant);
 
 /* Tuning knobs of the persistent kernel (benchmarks / profiling; results never
  * change): "dyn_thresh" 1..64 — re-fill idle lanes when fewer than this many lanes
- * of a wave are still traversing; "num_queues" 1..8 — work queues (8 = one per XCD);
+ * of a wave are still traversing (1 = only when the whole wave is done); "leaf_thresh"
+ * 1..64 — lanes waiting at a leaf are served once this many wait (64 = classic
+ * while-while traversal, 1 = if-if); "num_queues" 1..8 — work queues (8 = one per XCD);
  * "kernel_variant" as rtamd_set_kernel_variant. */
 int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value);
 

@@ -37,10 +37,17 @@ constexpr float EPSILON = 0.000001f;   // :11
 constexpr float T_PRIMARY0 = 1000000.0f;  // :199,211
 constexpr float T_HIT_LIMIT = 1000.0f;    // :206,219
 constexpr int BLOCK = 256;
+// k_persistent is latency-bound: occupancy matters (32 -> 20 waves per CU costs 13 %),
+// but forcing 8 waves per SIMD (<= 64 VGPRs) spills into the loop; 6 (<= 80) measured best.
+#ifndef RTAMD_WAVES_PER_EU
+#define RTAMD_WAVES_PER_EU 6
+#endif
+#define RTAMD_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(RTAMD_WAVES_PER_EU, RTAMD_WAVES_PER_EU)))
 
 struct SceneDev {
     const WideNode *nodes;
-    const TriRecord *tris;
+    const TriRecord *tris;        // == (char*)nodes + tri_byte_offset (same allocation)
+    uint32_t tri_byte_offset;
     const BigLeaf *big;
     const RefTriangle *tri_idx;   // reference 16-byte records (vertex indices + mat_idx)
     const float *normals;         // 3 per vertex or nullptr
@@ -73,7 +80,11 @@ struct JobParams {
     uint32_t *queues;             // n_queues counters, 16 dwords apart
     uint32_t n_queues;
     uint32_t dyn_thresh;
+    uint32_t leaf_thresh;
     uint32_t *spill;              // k_persistent: [wave slot][SPILL_STACK_ENTRIES][64] stack overflow area
+#ifdef RTAMD_EXP_STAMPS
+    unsigned long long *stamps;   // diagnostic build only: per wave {start, end, items, xcc} in 100 MHz ticks
+#endif
 };
 
 // ---------------------------------------------------------------------------
@@ -145,6 +156,7 @@ struct Trav {
     float u, v;
     uint32_t cur;   // node reference being visited, REF_NONE when the traversal is finished
     uint32_t sp;    // number of deferred references on this lane's stack
+    uint32_t pf0, pf1;  // landing registers of the prefetch touches (kept live until the next visit)
 };
 
 // Stack policies.  Entry e of thread tid lives at lds[e*BLOCK + tid] (ds_read/write_b32:
@@ -206,21 +218,82 @@ __device__ __forceinline__ bool slab(const Ray &r, float minx, float miny, float
 // into the nearer hit child, defer the other.  With dist = hit ? tmin : 1e30 the
 // shader's `dist0 < dist1` is  hit0 && (!hit1 || tmin0 < tmin1)  (a hit has
 // tmin < t <= 1e30), so equal distances visit child b first, exactly as :142-148.
+// Child selection + stack update shared by the two fetch paths of trav_inner.
+template <class Stack>
+__device__ __forceinline__ void trav_select(Trav &tr, Stack &st, uint32_t tid, bool hit0, bool hit1, float tmin0, float tmin1,
+                                            uint32_t ref_a, uint32_t ref_b) {
+    const bool a_first = hit0 && (!hit1 || tmin0 < tmin1);
+    const uint32_t near_ref = a_first ? ref_a : ref_b;
+    const uint32_t far_ref = a_first ? ref_b : ref_a;
+    if (hit0 && hit1) stack_push(st, tid, tr.sp, far_ref);
+    if (hit0 || hit1) tr.cur = near_ref;
+    else tr.cur = tr.sp ? stack_pop(st, tid, tr.sp) : REF_NONE;
+}
+
+// Touch-prefetch: one dword load from the record a child reference points to (node
+// record or first triangle record) pulls its cache line towards this CU's L1 while
+// the box tests of the current visit execute; the value is never used.
+// Measured on MI355X (tools/kbench.py, atrium 1080p): the two extra divergent dword
+// loads per visit cost more L1 tag look-ups than the latency they hide is worth
+// (k_static 0.59 -> 0.90 ms, k_persistent 0.55 -> 0.61 ms), i.e. the traversal is bound
+// by the vector-memory address/tag pipeline, not by load latency.  Kept for A/B only.
+#ifndef RTAMD_PREFETCH
+#define RTAMD_PREFETCH 0
+#endif
+__device__ __forceinline__ uint32_t touch_ref(const SceneDev &s, uint32_t ref) {
+    const uint32_t off = (ref & REF_LEAF_BIT) ? s.tri_byte_offset + (ref & REF_FIRST_MASK) * (uint32_t)sizeof(TriRecord)
+                                              : ref * (uint32_t)sizeof(WideNode);
+    return *reinterpret_cast<const volatile uint32_t *>(reinterpret_cast<const char *>(s.nodes) + off);
+}
+
+// Vector fetch: every lane loads its own 64-byte record (4 x global_load_dwordx4).
 template <bool COUNT, class Stack>
 __device__ __forceinline__ void trav_inner(const SceneDev &s, Trav &tr, Stack &st, uint32_t tid, uint32_t &nbox) {
     const float4 *np = reinterpret_cast<const float4 *>(&s.nodes[tr.cur]);
     const float4 q0 = np[0], q1 = np[1], q2 = np[2];
     const uint2 refs = *reinterpret_cast<const uint2 *>(&np[3]);
+#if RTAMD_PREFETCH
+    // keep the previous visit's landing registers allocated until here (their loads are
+    // older than the four above, so no extra wait), then re-use them for this visit
+    asm volatile("" ::"v"(tr.pf0), "v"(tr.pf1));
+    // big-leaf references (count field 0) index the overflow table, not a triangle: harmless, in-bounds touch
+    tr.pf0 = touch_ref(s, refs.x);
+    tr.pf1 = touch_ref(s, refs.y);
+#endif
     if (COUNT) nbox += 2;
     float tmin0, tmin1;
     const bool hit0 = slab(tr.ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tr.t, tmin0);
     const bool hit1 = slab(tr.ray, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr.t, tmin1);
-    const bool a_first = hit0 && (!hit1 || tmin0 < tmin1);
-    const uint32_t near_ref = a_first ? refs.x : refs.y;
-    const uint32_t far_ref = a_first ? refs.y : refs.x;
-    if (hit0 && hit1) stack_push(st, tid, tr.sp, far_ref);
-    if (hit0 || hit1) tr.cur = near_ref;
-    else tr.cur = tr.sp ? stack_pop(st, tid, tr.sp) : REF_NONE;
+    trav_select(tr, st, tid, hit0, hit1, tmin0, tmin1, refs.x, refs.y);
+}
+
+// Scalar fetch: all active lanes of the wave visit the SAME node (coherent rays near
+// the top of the tree: about half of all visits of a camera-ray wave).  The record
+// is read once through the scalar cache (s_load_dwordx16) into SGPRs, which the slab
+// arithmetic takes as scalar operands: no texture-address/L1 traffic, no VGPRs.
+typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
+template <bool COUNT, class Stack>
+__device__ __forceinline__ void trav_inner_uniform(const SceneDev &s, Trav &tr, Stack &st, uint32_t tid, uint32_t node, uint32_t &nbox) {
+    const_u32_ptr q = (const_u32_ptr)(uintptr_t)(s.nodes + node);
+    uint32_t w[14];
+#pragma unroll
+    for (int k = 0; k < 14; k++) w[k] = q[k];
+    if (COUNT) nbox += 2;
+    float tmin0, tmin1;
+    const bool hit0 = slab(tr.ray, __uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]),
+                           __uint_as_float(w[4]), __uint_as_float(w[5]), tr.t, tmin0);
+    const bool hit1 = slab(tr.ray, __uint_as_float(w[6]), __uint_as_float(w[7]), __uint_as_float(w[8]), __uint_as_float(w[9]),
+                           __uint_as_float(w[10]), __uint_as_float(w[11]), tr.t, tmin1);
+    trav_select(tr, st, tid, hit0, hit1, tmin0, tmin1, w[12], w[13]);
+}
+
+// One inner step for the lanes in `in` (ballot `m_in`): scalar path when they agree.
+template <bool COUNT, class Stack>
+__device__ __forceinline__ void trav_inner_step(const SceneDev &s, Trav &tr, Stack &st, uint32_t tid, bool in, unsigned long long m_in, uint32_t &nbox) {
+    const uint32_t c0 = __builtin_amdgcn_readlane(tr.cur, (int)__builtin_ctzll(m_in));   // node of the first lane in m_in
+    const bool uniform = __ballot(in && tr.cur == c0) == m_in;
+    if (uniform) { if (in) trav_inner_uniform<COUNT>(s, tr, st, tid, c0, nbox); }
+    else if (in) trav_inner<COUNT>(s, tr, st, tid, nbox);
 }
 
 // One leaf visit (:122-136): all triangles in ascending order, then pop.
@@ -421,7 +494,7 @@ enum : int { MODE_FUSED = 0, MODE_TRACE = 1 };
 // k_persistent — production kernel
 // ---------------------------------------------------------------------------
 template <int MODE, bool COUNT>
-__global__ void __launch_bounds__(BLOCK) k_persistent(const SceneDev s, const JobParams p) {
+__global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(const SceneDev s, const JobParams p) {
     __shared__ uint32_t lds_stack[LDS_STACK_ENTRIES * BLOCK];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     StackGlobal st;
@@ -433,10 +506,15 @@ __global__ void __launch_bounds__(BLOCK) k_persistent(const SceneDev s, const Jo
     bool drained = false;
     uint32_t tried = 0;
     const uint32_t home = p.n_queues > 1 ? xcc_id() % p.n_queues : 0u;
+#ifdef RTAMD_EXP_STAMPS
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long stamp_items = 0, stamp_last = stamp_t0, stamp_worst = 0, stamp_worst_item = 0;
+    unsigned long long stamp_inner = 0, stamp_inner_lanes = 0, stamp_leaf = 0, stamp_leaf_lanes = 0, stamp_uniform = 0;
+#endif
 
     uint32_t phase = PH_IDLE;
     Trav tr;
-    tr.cur = REF_NONE; tr.sp = 0; tr.t = 0; tr.idx = 0; tr.u = tr.v = 0;
+    tr.cur = REF_NONE; tr.sp = 0; tr.t = 0; tr.idx = 0; tr.u = tr.v = 0; tr.pf0 = tr.pf1 = 0;
     tr.ray = Ray{0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t out_index = 0;
     uint32_t nbox = 0, ntri = 0;
@@ -452,6 +530,14 @@ __global__ void __launch_bounds__(BLOCK) k_persistent(const SceneDev s, const Jo
                 uint32_t item = fetch_item(p, home, tried, lane);
                 if (item == 0xFFFFFFFFu) { drained = true; break; }
                 pool_item = item; pool_next = 0;
+#ifdef RTAMD_EXP_STAMPS
+                {   // with dyn_thresh == 1 a fetch happens only when the previous item is completely done
+                    unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    if (stamp_items && now - stamp_last > stamp_worst) { stamp_worst = now - stamp_last; stamp_worst_item = pool_item; }
+                    stamp_last = now;
+                }
+                stamp_items++;
+#endif
             }
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             const uint32_t avail = 64u - pool_next;
@@ -497,15 +583,37 @@ __global__ void __launch_bounds__(BLOCK) k_persistent(const SceneDev s, const Jo
             idle = __ballot(phase == PH_IDLE);
         }
         if (__ballot(phase != PH_IDLE) == 0ull) break;
-
         // ---- traverse until too few lanes are still busy ----
         const uint32_t thresh = drained ? 1u : p.dyn_thresh;
         for (;;) {
             const bool busy = tr.cur != REF_NONE;
             if ((uint32_t)__popcll(__ballot(busy)) < thresh) break;
-            if (busy) {
-                while (ref_is_inner(tr.cur)) trav_inner<COUNT>(s, tr, st, tid, nbox);
-                if (tr.cur != REF_NONE) trav_leaf<COUNT>(s, tr, st, tid, ntri);
+            // while-while with early leaf release: lanes that reached a leaf wait for the
+            // others to finish their inner-node steps, but only until `leaf_thresh` lanes
+            // are waiting (64 = classic while-while, 1 = if-if).  Per-lane order is
+            // untouched, so results are too; only the wave's lane utilisation changes.
+            for (;;) {
+                const bool in = busy && ref_is_inner(tr.cur);
+                const unsigned long long m_in = __ballot(in);
+                if (!m_in) break;
+                const unsigned long long m_leaf = __ballot(busy && !in && tr.cur != REF_NONE);
+                if ((uint32_t)__popcll(m_leaf) >= p.leaf_thresh) break;
+#ifdef RTAMD_EXP_STAMPS
+                stamp_inner++; stamp_inner_lanes += __popcll(m_in);
+                {
+                    const uint32_t c0 = __builtin_amdgcn_readfirstlane(tr.cur);
+                    if (__ballot(in && tr.cur == c0) == m_in) stamp_uniform++;
+                }
+#endif
+                trav_inner_step<COUNT>(s, tr, st, tid, in, m_in, nbox);
+            }
+            {
+                const bool lf = busy && tr.cur != REF_NONE && !ref_is_inner(tr.cur);
+#ifdef RTAMD_EXP_STAMPS
+                const unsigned long long m = __ballot(lf);
+                if (m) { stamp_leaf++; stamp_leaf_lanes += __popcll(m); }
+#endif
+                if (lf) trav_leaf<COUNT>(s, tr, st, tid, ntri);
             }
         }
 
@@ -543,6 +651,15 @@ __global__ void __launch_bounds__(BLOCK) k_persistent(const SceneDev s, const Jo
             }
         }
     }
+#ifdef RTAMD_EXP_STAMPS
+    if (lane == 0 && p.stamps) {
+        unsigned long long *o = p.stamps + 8ull * (blockIdx.x * (BLOCK / 64) + (tid >> 6));
+        o[4] = stamp_inner; o[5] = stamp_inner_lanes; o[6] = stamp_leaf | (stamp_uniform << 32); o[7] = stamp_leaf_lanes;
+        unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (now - stamp_last > stamp_worst) { stamp_worst = now - stamp_last; stamp_worst_item = pool_item; }
+        o[0] = stamp_t0; o[1] = now; o[2] = stamp_items | (stamp_worst << 32); o[3] = xcc_id() | (stamp_worst_item << 8);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -552,12 +669,17 @@ __global__ void __launch_bounds__(BLOCK) k_persistent(const SceneDev s, const Jo
 template <int MODE, bool COUNT>
 __global__ void __launch_bounds__(BLOCK) k_static(const SceneDev s, const JobParams p) {
     __shared__ uint32_t lds_stack[LDS_STACK_ENTRIES * BLOCK];
+#ifdef RTAMD_EXP_PAD_LDS   // occupancy experiment only: waste LDS to cap resident blocks
+    __shared__ uint32_t lds_pad[RTAMD_EXP_PAD_LDS / 4];
+    if (p.n_items == 0xFFFFFFFFu) lds_pad[threadIdx.x] = 1, p.rgba[0] = (float)lds_pad[threadIdx.x ^ 1];
+#endif
     StackScratch st;
     st.lds = lds_stack;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t item = blockIdx.x * (BLOCK / 64) + (tid >> 6);
     if (item >= p.n_items) return;
     Trav tr;
+    tr.pf0 = tr.pf1 = 0;
     uint32_t nbox = 0, ntri = 0;
     if (MODE == MODE_TRACE) {
         const uint64_t ri = (uint64_t)item * 64u + lane;

@@ -46,9 +46,16 @@ struct rtamd_context {
     DevBuf queues;
     DevBuf spill;  // traversal-stack overflow of the persistent kernel, one slice per resident wave
     DevBuf ipv;  // 16 floats for k_generate_rays
+#ifdef RTAMD_EXP_STAMPS
+    DevBuf stamps;
+#endif
     SceneDev sdev{};
     rtamd_scene_info info{};
-    uint32_t dyn_thresh = 40;
+    // measured defaults (tools/kbench.py): coherent camera/shadow rays run best without lane
+    // re-fill (1), incoherent ray streams with re-fill below 32 busy lanes; leaves are
+    // released when 4 lanes wait
+    uint32_t dyn_thresh_fused = 1, dyn_thresh_trace = 32;
+    uint32_t leaf_thresh = 4;
     uint32_t n_queues = 8;
 };
 
@@ -121,8 +128,12 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     if (p.n_items == 0) return RTAMD_OK;
     p.queues = (uint32_t *)ctx->queues.p;
     p.n_queues = ctx->n_queues;
-    p.dyn_thresh = ctx->dyn_thresh;
+    p.dyn_thresh = mode == MODE_FUSED ? ctx->dyn_thresh_fused : ctx->dyn_thresh_trace;
+    p.leaf_thresh = ctx->leaf_thresh;
     p.spill = (uint32_t *)ctx->spill.p;
+#ifdef RTAMD_EXP_STAMPS
+    p.stamps = (unsigned long long *)ctx->stamps.p;
+#endif
     hipStream_t st = ctx->stream;
     const SceneDev &s = ctx->sdev;
     if (ctx->variant == 0) HIP_TRY(ctx, hipMemsetAsync(ctx->queues.p, 0, ctx->queues.bytes, st));
@@ -227,14 +238,14 @@ int rtamd_context_create(int device_ordinal, rtamd_context **out_ctx) {
         size_t waves = (size_t)ctx->num_cu * max_per_cu * (BLOCK / 64);
         if ((rc = dev_alloc(ctx, ctx->spill, waves * SPILL_STACK_ENTRIES * 64 * sizeof(uint32_t)))) return bail(rc);
     }
+#ifdef RTAMD_EXP_STAMPS
+    if ((rc = dev_alloc(ctx, ctx->stamps, 65536 * 64))) return bail(rc);
+    (void)hipMemset(ctx->stamps.p, 0, ctx->stamps.bytes);
+#endif
     const uint32_t white = 0xFFFFFFFFu;
     if ((rc = dev_upload(ctx, ctx->white, &white, 4))) return bail(rc);
     if ((rc = dev_alloc(ctx, ctx->queues, 8 * 64))) return bail(rc);
     if ((rc = dev_alloc(ctx, ctx->ipv, 64))) return bail(rc);
-    const char *env = std::getenv("RTAMD_DYN_THRESH");
-    if (env) { int v = std::atoi(env); if (v >= 1 && v <= 64) ctx->dyn_thresh = (uint32_t)v; }
-    env = std::getenv("RTAMD_NUM_QUEUES");
-    if (env) { int v = std::atoi(env); if (v >= 1 && v <= 8) ctx->n_queues = (uint32_t)v; }
     *out_ctx = ctx;
     return RTAMD_OK;
 }
@@ -280,7 +291,10 @@ int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value) {
     if (!name) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "option name is NULL");
     if (!std::strcmp(name, "dyn_thresh")) {
         if (value < 1 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "dyn_thresh must be 1..64");
-        ctx->dyn_thresh = (uint32_t)value;
+        ctx->dyn_thresh_fused = ctx->dyn_thresh_trace = (uint32_t)value;
+    } else if (!std::strcmp(name, "leaf_thresh")) {
+        if (value < 1 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "leaf_thresh must be 1..64");
+        ctx->leaf_thresh = (uint32_t)value;
     } else if (!std::strcmp(name, "num_queues")) {
         if (value < 1 || value > 8) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "num_queues must be 1..8");
         ctx->n_queues = (uint32_t)value;
@@ -377,8 +391,16 @@ int rtamd_upload_scene(rtamd_context *ctx, const rtamd_scene_desc *sc) {
             }
         }
 
-        if ((rc = dev_upload(ctx, ctx->nodes, wide.data(), wide.size() * sizeof(WideNode)))) return rc;
-        if ((rc = dev_upload(ctx, ctx->tris, recs.data(), recs.size() * sizeof(TriRecord)))) return rc;
+        // node records and triangle records share ONE allocation (nodes first, triangles
+        // after them, 128-byte aligned) so that a 32-bit byte offset from one base reaches
+        // either kind: the prefetch touch of a child needs no 64-bit address arithmetic.
+        const size_t node_bytes = (wide.size() * sizeof(WideNode) + 127) & ~(size_t)127;
+        const size_t tri_bytes = recs.size() * sizeof(TriRecord);
+        if (node_bytes + tri_bytes > 0xFFFFFFF0ull) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "scene geometry exceeds the 4 GiB device layout limit");
+        if ((rc = dev_alloc(ctx, ctx->nodes, node_bytes + tri_bytes))) return rc;
+        HIP_TRY(ctx, hipMemcpy(ctx->nodes.p, wide.data(), wide.size() * sizeof(WideNode), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy((char *)ctx->nodes.p + node_bytes, recs.data(), tri_bytes, hipMemcpyHostToDevice));
+        ctx->tris.release();
         if ((rc = dev_upload(ctx, ctx->big, big.data(), big.size() * sizeof(BigLeaf)))) return rc;
         if ((rc = dev_upload(ctx, ctx->tri_idx, tris, (size_t)n_tris * sizeof(RefTriangle)))) return rc;
         ctx->normals.release(); ctx->texcoords.release();
@@ -387,7 +409,8 @@ int rtamd_upload_scene(rtamd_context *ctx, const rtamd_scene_desc *sc) {
 
         SceneDev &s = ctx->sdev;
         s.nodes = (const WideNode *)ctx->nodes.p;
-        s.tris = (const TriRecord *)ctx->tris.p;
+        s.tris = (const TriRecord *)((const char *)ctx->nodes.p + node_bytes);
+        s.tri_byte_offset = (uint32_t)node_bytes;
         s.big = (const BigLeaf *)ctx->big.p;
         s.tri_idx = (const RefTriangle *)ctx->tri_idx.p;
         s.normals = (const float *)ctx->normals.p;
@@ -592,6 +615,16 @@ int rtamd_get_scene_info(const rtamd_context *ctx, rtamd_scene_info *info) {
     *info = ctx->info;
     return RTAMD_OK;
 }
+
+#ifdef RTAMD_EXP_STAMPS
+/* diagnostic build only (not declared in include/rtamd.h) */
+int rtamd_exp_read_stamps(rtamd_context *ctx, unsigned long long *out, uint32_t waves) {
+    if (!ctx || !out || waves > 65536) return RTAMD_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->stamps.p, (size_t)waves * 64, hipMemcpyDeviceToHost));
+    return RTAMD_OK;
+}
+#endif
 
 int rtamd_last_kernel_ms(rtamd_context *ctx, float *ms) {
     if (!ctx || !ms) return RTAMD_ERR_INVALID_ARGUMENT;

@@ -1,0 +1,216 @@
+"""GPU tests of the C-ABI beyond fixture parity: error behaviour, tile sharding +
+assembly, on-device ray generation, and full-size (BASELINE configs) checks through
+size-independent properties: scheduling knobs and kernel variants never change a
+bit of the output, shards re-assemble to the single-GPU frame, and sampled pixels
+agree with the CPU oracle."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+
+from common import bits, load_golden, rgb_err_255
+from raytracer_amd import host, scenes
+from raytracer_amd.renderer import HipRayTracer, RtamdError, assemble_tiles_host
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def atrium():
+    tri, pos, uv, nrm, cam = scenes.atrium()
+    m = host.Model.from_arrays(tri, pos, uv, nrm)
+    m.build_bvh()
+    d = np.asarray(cam["direction"], np.float32)
+    d /= np.linalg.norm(d)
+    camera = host.Camera(16 / 9, fov=math.radians(cam["fov_deg"]), position=cam["position"], direction=d)
+    return m.scene_arrays(), camera, (scenes.checker_texture(), scenes.noise_texture())
+
+
+def test_errors():
+    t = HipRayTracer(0)
+    try:
+        with pytest.raises(RtamdError) as e:
+            t.trace(np.zeros((4, 3), np.float32), np.ones((4, 3), np.float32))
+        assert e.value.code == -3                                   # RTAMD_ERR_NO_SCENE
+        g = load_golden("cube")
+        with pytest.raises(RtamdError) as e:
+            t.upload_scene({"nodes": g["nodes"][:0], "triangles": g["triangles"], "positions": g["positions"]})
+        assert e.value.code == -2                                   # RTAMD_ERR_EMPTY_SCENE
+        bad = g["nodes"].copy()
+        bad["a"][0] = 10_000
+        with pytest.raises(RtamdError) as e:
+            t.upload_scene({"nodes": bad, "triangles": g["triangles"], "positions": g["positions"]})
+        assert e.value.code == -4 and "out of range" in str(e.value)  # RTAMD_ERR_MALFORMED_SCENE
+        cyc = g["nodes"].copy()
+        inner = np.where(cyc["is_leaf"] == 0)[0]
+        cyc["b"][inner[-1]] = 0                                     # child points back at the root
+        with pytest.raises(RtamdError) as e:
+            t.upload_scene({"nodes": cyc, "triangles": g["triangles"], "positions": g["positions"]})
+        assert e.value.code == -4
+        tb = g["triangles"].copy()
+        tb["p2"][3] = 99
+        with pytest.raises(RtamdError) as e:
+            t.upload_scene({"nodes": g["nodes"], "triangles": tb, "positions": g["positions"]})
+        assert e.value.code == -4
+        t.upload_scene(g["scene"])
+        with pytest.raises(RtamdError) as e:
+            t.render(8, 8, dir=np.ones((64, 3), np.float32), org=np.zeros((64, 3), np.float32), has_normals=True)
+        assert e.value.code == -1                                   # scene has no normals
+        with pytest.raises(RtamdError):
+            t.upload_texture(2, np.zeros((2, 2, 3), np.uint8))
+        with pytest.raises(RtamdError):
+            t.set_option("no_such_option", 1)
+        assert t.trace(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32)).shape == (0, 4)
+    finally:
+        t.close()
+
+
+def test_scene_info_and_single_leaf_root(tracer):
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    m = host.Model.from_arrays(np.array([[0, 1, 2, 0]], np.uint32), pos)
+    m.build_bvh()
+    tracer.upload_scene(m.scene_arrays())
+    info = tracer.scene_info()
+    assert (info.triangle_count, info.inner_node_count, info.max_depth) == (1, 0, 0)
+    hits = tracer.trace(np.array([[0.2, 0.2, 1], [5, 5, 1]], np.float32), np.array([[0, 0, -1], [0, 0, -1]], np.float32))
+    assert hits[0, 0] == 1.0 and bits(hits)[0, 3] == 0 and hits[1, 0] == np.float32(1e30)
+
+
+def test_big_leaves_use_the_overflow_table(tracer, oracle_a):
+    """20 identical-centroid triangles cannot be split (one-sided partition, bvh.rs:232):
+    one leaf with count 20 > 15 exercises the BigLeaf path."""
+    pos = np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0]], np.float32)
+    k = 20
+    allpos = np.concatenate([pos + np.float32([0, 0, 0.01 * i]) * 0 for i in range(k)])  # identical triangles
+    tri = np.array([[3 * i, 3 * i + 1, 3 * i + 2, 0] for i in range(k)], np.uint32)
+    m = host.Model.from_arrays(tri, allpos)
+    m.build_bvh()
+    sc = m.scene_arrays()
+    assert sc["nodes"]["b"].max() == k
+    tracer.upload_scene(sc)
+    assert tracer.scene_info().big_leaf_count == 1
+    rng = np.random.default_rng(0)
+    org = np.concatenate([rng.uniform(-1, 1, (256, 2)), np.full((256, 1), 2.0)], 1).astype(np.float32)
+    d = np.tile(np.float32([0, 0, -1]), (256, 1))
+    assert np.array_equal(bits(tracer.trace(org, d)), bits(oracle_a.trace(sc, org, d)["hits"]))
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_tile_shards_assemble_to_the_full_frame(tracer, world):
+    g = load_golden("bunny")
+    h, w = g["dir"].shape[:2]
+    tracer.upload_scene(g["scene"])
+    full = tracer.render(w, h, dir=g["dir"], org=g["org"], has_normals=1)
+    parts = [tracer.render(w, h, dir=g["dir"], org=g["org"], has_normals=1, tile_rank=r, tile_world=world) for r in range(world)]
+    per_rank = tracer.tiles_per_rank(w, h, world) * 1024
+    pad = lambda a: np.concatenate([a, np.zeros((per_rank - len(a),) + a.shape[1:], a.dtype)])
+    frame = assemble_tiles_host([pad(p["rgba"]) for p in parts], w, h, world, 4).reshape(-1, 4)
+    assert np.array_equal(bits(frame), bits(full["rgba"]))
+    ids = assemble_tiles_host([pad(p["hit_id"].reshape(-1, 1)) for p in parts], w, h, world, 1).reshape(-1)
+    assert np.array_equal(ids, full["hit_id"])
+    # device-side assembly (root side of the RCCL gather)
+    import torch
+    gathered = torch.from_numpy(np.concatenate([pad(p["rgba"]) for p in parts])).cuda()
+    out = torch.zeros((w * h, 4), dtype=torch.float32, device="cuda")
+    tracer.assemble_tiles_device(gathered.data_ptr(), w, h, world, 4, out.data_ptr())
+    tracer.synchronize()
+    assert np.array_equal(bits(out.cpu().numpy()), bits(full["rgba"]))
+
+
+def test_on_device_ray_generation_equals_host_and_oracle(tracer, oracle_a):
+    cam = host.Camera(16 / 9, fov=math.radians(75), position=(0.5, 1.5, -2.0), direction=(0.2, -0.1, 0.97))
+    inv = cam.inv_proj_view()
+    d_host, o_host = cam.primary_rays(160, 90)
+    d_dev = tracer.generate_rays(160, 90, inv)
+    assert np.array_equal(bits(d_dev), bits(d_host))
+    assert np.array_equal(bits(d_dev), bits(oracle_a.raycreate(160, 90, inv, host.NEAR, host.FAR)))
+    g = load_golden("teapot")
+    tracer.upload_scene(g["scene"])
+    c2 = host.Camera(160 / 90, position=g["org"][0, 0], direction=g["dir"][60, 80])
+    a = tracer.render(160, 90, camera=(c2.inv_proj_view(), c2.position))
+    dd, oo = c2.primary_rays(160, 90)
+    b = tracer.render(160, 90, dir=dd, org=oo)
+    assert np.array_equal(bits(a["rgba"]), bits(b["rgba"])) and np.array_equal(a["hit_id"], b["hit_id"])
+    assert (a["hit_id"] != 0xFFFFFFFF).sum() > 500
+
+
+def test_full_size_atrium_properties(tracer, oracle_a, atrium):
+    """BASELINE config 3 (Sponza-class, 1080p, primary + shadow): every scheduling
+    variant produces the same bits; sampled pixel rows equal the CPU oracle."""
+    sc, camera, tex = atrium
+    W, H = 1920, 1080
+    tracer.upload_scene(sc)
+    tracer.upload_texture(0, tex[0]); tracer.upload_texture(1, tex[1])
+    inv = camera.inv_proj_view()
+    ref = None
+    try:
+        for opts in ({"kernel_variant": 1}, {"kernel_variant": 0, "dyn_thresh": 1, "leaf_thresh": 4, "num_queues": 8},
+                     {"kernel_variant": 0, "dyn_thresh": 40, "leaf_thresh": 64, "num_queues": 1},
+                     {"kernel_variant": 0, "dyn_thresh": 64, "leaf_thresh": 1, "num_queues": 3}):
+            for k, v in opts.items():
+                tracer.set_option(k, v)
+            r = tracer.render(W, H, camera=(inv, camera.position), has_tex_coords=1, has_normals=1, want=("rgba", "hit_id", "hit_t", "counts"))
+            if ref is None:
+                ref = r
+            else:
+                for key in ("rgba", "hit_id", "hit_t", "counts"):
+                    assert np.array_equal(ref[key].view(np.uint32), r[key].view(np.uint32)), (opts, key)
+    finally:
+        for k, v in {"kernel_variant": 0, "dyn_thresh": 1, "leaf_thresh": 4, "num_queues": 8}.items():
+            tracer.set_option(k, v)
+        tracer.set_option("dyn_thresh", 1)
+    hit = ref["hit_id"] != 0xFFFFFFFF
+    assert 0.9 < hit.mean() < 0.99 and np.all(ref["rgba"][:, 3] == 1)
+    dirs, orgs = camera.primary_rays(W, H)
+    rows = [7, 300, 541, 700, 1079]
+    sel = np.concatenate([np.arange(y * W, (y + 1) * W) for y in rows])
+    a = oracle_a.render(sc, dirs.reshape(-1, 3)[sel], orgs.reshape(-1, 3)[sel], 1, 1, tex[0], tex[1], nthreads=8)
+    assert np.array_equal(a["hit_id"], ref["hit_id"][sel]) and np.array_equal(bits(a["hit_t"]), bits(ref["hit_t"][sel]))
+    assert np.array_equal(a["counts"], ref["counts"][sel])
+    assert rgb_err_255(a["rgba"], ref["rgba"][sel]).max() <= 0.05
+
+
+def test_full_size_bunny_class_1080p(tracer, oracle_a):
+    """BASELINE config 2: bunny subdivided twice (80 016 triangles), 1080p, white albedo."""
+    g = load_golden("bunny")
+    t = g["triangles"]
+    tri, pos, nrm = scenes.subdivide(np.stack([t["p0"], t["p1"], t["p2"], t["mat_idx"]], 1), g["positions"], g["normals"], levels=2)
+    m = host.Model.from_arrays(tri, pos, None, nrm)
+    m.build_bvh()
+    sc = m.scene_arrays()
+    tracer.upload_scene(sc)
+    white = np.full((1, 1, 3), 255, np.uint8)
+    tracer.upload_texture(0, white); tracer.upload_texture(1, white)
+    lo, hi = pos.min(0), pos.max(0)
+    c = (lo + hi) / 2
+    eye = c + 0.9 * np.linalg.norm(hi - lo) / 2 * np.float32([0.7, 0.3, 0.65])
+    d = (c - eye) / np.linalg.norm(c - eye)
+    cam = host.Camera(16 / 9, fov=math.radians(60), position=eye, direction=d)
+    W, H = 1920, 1080
+    r = tracer.render(W, H, camera=(cam.inv_proj_view(), cam.position), has_normals=1)
+    assert (r["hit_id"] != 0xFFFFFFFF).mean() > 0.2
+    dirs, orgs = cam.primary_rays(W, H)
+    sel = np.concatenate([np.arange(y * W, (y + 1) * W) for y in (200, 540, 541, 800)])
+    a = oracle_a.render(sc, dirs.reshape(-1, 3)[sel], orgs.reshape(-1, 3)[sel], 0, 1, nthreads=8)
+    assert np.array_equal(a["hit_id"], r["hit_id"][sel]) and np.array_equal(bits(a["hit_t"]), bits(r["hit_t"][sel]))
+    assert rgb_err_255(a["rgba"], r["rgba"][sel]).max() <= 0.05
+
+
+def test_soup_incoherent_trace_matches_oracle(tracer, oracle_a):
+    """BASELINE config 4 stand-in at test size (200 k of the 10 M triangles): incoherent BVH,
+    no normals / uvs, random rays; bit-exact hit records."""
+    tri, pos, _ = scenes.triangle_soup(200_000, seed=1, extent=30.0)
+    m = host.Model.from_arrays(tri, pos)
+    m.build_bvh()
+    sc = m.scene_arrays()
+    tracer.upload_scene(sc)
+    rng = np.random.default_rng(2)
+    n = 100_000
+    org = rng.uniform(-35, 35, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d.astype(np.float32)
+    got = tracer.trace(org, d)
+    want = oracle_a.trace(sc, org, d, nthreads=8)["hits"]
+    assert (want[:, 0] < 1e30).mean() > 0.3
+    assert np.array_equal(bits(got), bits(want))

@@ -52,8 +52,10 @@ def main():
     for r in range(args.rounds + 2):
         for name, o in arms:
             tr.set_option("kernel_variant", int(o.get("variant", 0)))
-            tr.set_option("dyn_thresh", int(o.get("dyn_thresh", 40)))
+            mode = o.get("mode", "fused")
+            tr.set_option("dyn_thresh", int(o.get("dyn_thresh", 1 if mode == "fused" else 32)))
             tr.set_option("num_queues", int(o.get("num_queues", 8)))
+            tr.set_option("leaf_thresh", int(o.get("leaf_thresh", 4)))
             mode = o.get("mode", "fused")
             if mode == "fused":
                 tr.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=has_tc, has_normals=has_n, rgba_ptr=d_rgba.data_ptr())

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Diagnostic (GPU box): wave lifetime histogram of k_persistent from the
+-DRTAMD_EXP_STAMPS build.  RTAMD_DEVICE_LIB must point at that build."""
+import ctypes, os, sys
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch, bench
+from raytracer_amd.renderer import HipRayTracer
+model, camera, W, H, tex = bench.build_workload("atrium_1080p")
+sc = model.scene_arrays(); dev = torch.device("cuda", 0)
+tr = HipRayTracer(0); tr.upload_scene(sc)
+for slot, t in enumerate(tex): tr.upload_texture(slot, t)
+n = W * H
+d_dir = torch.empty((n, 3), dtype=torch.float32, device=dev); tr.generate_rays_device(W, H, camera.inv_proj_view(), d_dir.data_ptr())
+d_org = torch.tensor(np.asarray(camera.position, np.float32), device=dev).repeat(n, 1).contiguous()
+d_rgba = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+tr.set_option('leaf_thresh', 8)
+for th, nq in ((1, 1), (1, 8)):
+    tr.set_option("dyn_thresh", th); tr.set_option("num_queues", nq)
+    for _ in range(3):
+        tr.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=True, has_normals=True, rgba_ptr=d_rgba.data_ptr())
+    ms = tr.last_kernel_ms()
+    waves = 8192
+    buf = np.zeros((waves, 8), np.uint64)
+    tr._lib.rtamd_exp_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    tr._check(tr._lib.rtamd_exp_read_stamps(tr._h, buf.ctypes.data, waves))
+    b = buf[buf[:, 1] > 0].copy()
+    worst = (b[:, 2] >> np.uint64(32)).astype(np.float64) / 100.0
+    worst_item = (b[:, 3] >> np.uint64(8)).astype(np.int64)
+    b[:, 2] &= np.uint64(0xFFFFFFFF); b[:, 3] &= np.uint64(0xFF)
+    alive_us = (b[:, 1] - b[:, 0]) / 100.0
+    uniform = (b[:, 6] >> np.uint64(32)).astype(np.float64); b[:, 6] &= np.uint64(0xFFFFFFFF)
+    inner, inner_l, leaf, leaf_l = (b[:, k].astype(np.float64) for k in (4, 5, 6, 7))
+    print(f'   wave-uniform inner iterations: {uniform.sum()/inner.sum():.3f}')
+    print(f"   wave-level iterations per wave: inner mean {inner.mean():.0f}, leaf {leaf.mean():.0f}; lane util inner {inner_l.sum()/(64*inner.sum()):.3f} leaf {leaf_l.sum()/(64*leaf.sum()):.3f}; "
+          f"us per inner iteration: mean {(alive_us/inner).mean():.3f} p10 {np.percentile(alive_us/inner,10):.3f} p90 {np.percentile(alive_us/inner,90):.3f}")
+    slow = np.argsort(-alive_us)[:5]
+    for o in slow:
+        print(f"   slowest wave: alive {alive_us[o]:.0f} us items {b[o,2]} inner {inner[o]:.0f} leaf {leaf[o]:.0f} util {inner_l[o]/(64*inner[o]):.2f} us/inner {alive_us[o]/inner[o]:.3f}")
+    if th == 1:
+        order = np.argsort(-worst)[:12]
+        tiles_x = (W + 31) // 32
+        for o in order:
+            it = worst_item[o]; j, sub = it >> 4, it & 15
+            x = ((j % tiles_x) * 4 + (sub & 3)) * 8; y = ((j // tiles_x) * 4 + (sub >> 2)) * 8
+            print(f"   slow item {it} at px ({x},{y}) took {worst[o]:.0f} us")
+        print("   worst-item-per-wave us: p50/p90/p99/max", np.percentile(worst, [50, 90, 99, 100]).round(0))
+    t0 = b[:, 0].min(); st = (b[:, 0] - t0) / 100.0; en = (b[:, 1] - t0) / 100.0  # us
+    print(f"thresh={th} queues={nq}: kernel {ms*1e3:.0f} us, waves {len(b)}, start p50/p99/max {np.percentile(st,50):.1f}/{np.percentile(st,99):.1f}/{st.max():.1f} us, "
+          f"end min/p10/p50/p90/max {en.min():.0f}/{np.percentile(en,10):.0f}/{np.percentile(en,50):.0f}/{np.percentile(en,90):.0f}/{en.max():.0f} us, "
+          f"items/wave min/mean/max {b[:,2].min()}/{b[:,2].mean():.1f}/{b[:,2].max()}, mean alive {np.mean(en-st):.0f} us")
+    for x in range(8):
+        m = b[:, 3] == x
+        print(f"   xcc {x}: waves {m.sum()}, items {int(b[m,2].sum())}, end p50 {np.percentile(en[m],50):.0f} max {en[m].max():.0f}")
