@@ -220,6 +220,12 @@ def main():
                               "frac": round(alg_ops / (launch_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS, 5)}},
     }
 
+    # HBM-side traffic of the same kernel from the committed rocprofv3 --pmc passes
+    # (cannot be collected live: PMC runs serialise kernels); see profiles/.
+    tpath = os.path.join(REPO, "profiles", f"traffic_{args.workload}.json")
+    if world == 1 and args.variant == 0 and os.path.exists(tpath):
+        out["roofline"]["traffic"] = json.load(open(tpath))["traffic_bytes_per_launch"]
+
     if world == 1 and not args.no_cpu_baseline:
         # oracle A (the CPU restatement) on the same frame, bounded: every 2nd pixel row
         sys.path.insert(0, os.path.join(REPO, "tests"))
