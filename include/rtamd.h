@@ -201,11 +201,20 @@ int rtamd_last_kernel_ms(rtamd_context *ctx, float *ms);
 int rtamd_set_kernel_variant(rtamd_context *ctx, int variant);
 
 /* Tuning knobs of the persistent kernel (benchmarks / profiling; results never
- * change): "dyn_thresh" 1..64 — re-fill idle lanes when fewer than this many lanes
- * of a wave are still traversing (1 = only when the whole wave is done); "leaf_thresh"
- * 1..64 — lanes waiting at a leaf are served once this many wait (64 = classic
- * while-while traversal, 1 = if-if); "num_queues" 1..8 — work queues (8 = one per XCD);
- * "kernel_variant" as rtamd_set_kernel_variant. */
+ * change):
+ *  "dyn_thresh" 1..64   re-fill idle lanes when fewer than this many lanes of a wave are
+ *                       still traversing (1 = only when the whole wave is done);
+ *  "leaf_thresh" 1..64  lanes waiting at a leaf are served once this many wait (64 = classic
+ *                       while-while traversal, 1 = if-if);
+ *  "num_queues" 1..32   work-queue counters (8 = one per XCD);
+ *  "queue_stride" 1..4096  u32 words between the counters (default 64 = 256 B, one memory
+ *                       channel each);
+ *  "chunk" 1..64        schedule positions a wave takes per atomic (default 1);
+ *  "prio_thresh" >= 0   0 = off (default); else a wave raises its issue priority once its
+ *                       current item has cost this many loop-iteration units (again at x3, x7);
+ *  "adaptive_order" 0/1 schedule a frame's items by the cost counted for them in the previous
+ *                       launch of the same size, longest first (default 0: measured slower);
+ *  "kernel_variant"     as rtamd_set_kernel_variant. */
 int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value);
 
 const char *rtamd_version(void);

@@ -81,6 +81,11 @@ struct JobParams {
     uint32_t n_queues;
     uint32_t dyn_thresh;
     uint32_t leaf_thresh;
+    uint32_t queue_stride;        // u32 words between queue counters
+    uint32_t chunk;               // schedule positions taken per atomic
+    uint32_t prio_thresh;         // 0 = off; else a wave raises its issue priority when its item has cost this much work (x2, x4)
+    const uint32_t *item_order;   // schedule position -> item, or nullptr (identity)
+    uint32_t *item_cost;          // per item: weighted wave-level loop iterations spent on it this frame (feeds the next schedule), or nullptr
     uint32_t *spill;              // k_persistent: [wave slot][SPILL_STACK_ENTRIES][64] stack overflow area
 #ifdef RTAMD_EXP_STAMPS
     unsigned long long *stamps;   // diagnostic build only: per wave {start, end, items, xcc} in 100 MHz ticks
@@ -462,9 +467,11 @@ __device__ __forceinline__ PixelRef item_pixel(const JobParams &p, uint32_t item
 }
 
 // ---------------------------------------------------------------------------
-// queues: n_queues counters (64 bytes apart); queue k serves items
-// [k*n/nq, (k+1)*n/nq).  A wave starts on the queue of its XCD and steals from
-// the others when its own is empty, so placement only affects L2 locality.
+// queues: n_queues counters (64 bytes apart) over ONE schedule (item_order: items
+// sorted by the cost the previous frame measured for them, longest first — LPT
+// scheduling; identity on the first frame).  A wave starts on the counter of its
+// XCD and steals from the others when that one is exhausted; which wave renders
+// which item never changes a result bit.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t xcc_id() {
     uint32_t v;
@@ -472,19 +479,27 @@ __device__ __forceinline__ uint32_t xcc_id() {
     return v & 7u;
 }
 
-__device__ __forceinline__ uint32_t fetch_item(const JobParams &p, uint32_t home, uint32_t &tried, uint32_t lane) {
-    while (tried < p.n_queues) {
-        uint32_t k = home + tried;
+struct QueueCursor { uint32_t tried, k, v_next, v_end; };
+
+__device__ __forceinline__ uint32_t fetch_item(const JobParams &p, uint32_t home, QueueCursor &q, uint32_t lane) {
+    for (;;) {
+        if (q.v_next < q.v_end) {
+            // queue k serves schedule positions k, k + nq, k + 2nq, ...: every queue sees the
+            // same profile of the schedule
+            const uint32_t pos = q.v_next * p.n_queues + q.k;
+            q.v_next++;
+            if (pos < p.n_items) return p.item_order ? p.item_order[pos] : pos;
+            q.v_next = q.v_end;   // this queue is exhausted
+            q.tried++;
+        }
+        if (q.tried >= p.n_queues) return 0xFFFFFFFFu;
+        uint32_t k = home + q.tried;
         if (k >= p.n_queues) k -= p.n_queues;
-        uint32_t lo = (uint32_t)(((uint64_t)p.n_items * k) / p.n_queues);
-        uint32_t hi = (uint32_t)(((uint64_t)p.n_items * (k + 1)) / p.n_queues);
         uint32_t v = 0;
-        if (lane == 0) v = atomicAdd(&p.queues[k * 16u], 1u);
+        if (lane == 0) v = atomicAdd(&p.queues[k * p.queue_stride], p.chunk);
         v = __builtin_amdgcn_readfirstlane(v);
-        if (v < hi - lo) return lo + v;
-        tried++;
+        q.k = k; q.v_next = v; q.v_end = v + p.chunk;
     }
-    return 0xFFFFFFFFu;
 }
 
 enum : uint32_t { PH_IDLE = 0, PH_PRIMARY = 1, PH_SHADOW = 2 };
@@ -504,12 +519,20 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
     // wave-uniform pool of pending pixels / rays: item `pool_item`, lanes [pool_next, 64)
     uint32_t pool_item = 0, pool_next = 64;
     bool drained = false;
-    uint32_t tried = 0;
-    const uint32_t home = p.n_queues > 1 ? xcc_id() % p.n_queues : 0u;
+    QueueCursor qc{0, 0, 0, 0};
+    // home queue: the wave's XCD, and with more than 8 queues one of that XCD's nq/8 counters
+    const uint32_t home = p.n_queues > 8 ? (xcc_id() + 8u * ((blockIdx.x >> 3) % (p.n_queues >> 3))) % p.n_queues
+                                         : (p.n_queues > 1 ? xcc_id() % p.n_queues : 0u);
+    uint32_t item_work = 0;   // wave-level loop iterations since pool_item was fetched (contention-free cost)
+    bool item_live = false;
+    uint32_t prio_level = 0, prio_next = p.prio_thresh ? p.prio_thresh : 0xFFFFFFFFu;
 #ifdef RTAMD_EXP_STAMPS
     const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long stamp_items = 0, stamp_last = stamp_t0, stamp_worst = 0, stamp_worst_item = 0;
     unsigned long long stamp_inner = 0, stamp_inner_lanes = 0, stamp_leaf = 0, stamp_leaf_lanes = 0, stamp_uniform = 0;
+    unsigned long long tm_inner = 0, tm_leaf = 0, snap_tmi = 0, snap_tml = 0;
+    const unsigned long long tm_start = __builtin_amdgcn_s_memtime();
+    unsigned long long snap_inner = 0, snap_leaf = 0, snap_uniform = 0, snap_lanes = 0, w_inner = 0, w_leaf = 0, w_uniform = 0, w_lanes = 0;
 #endif
 
     uint32_t phase = PH_IDLE;
@@ -527,17 +550,32 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
         unsigned long long idle = __ballot(phase == PH_IDLE);
         while (idle != 0ull && !drained) {
             if (pool_next >= 64u) {
-                uint32_t item = fetch_item(p, home, tried, lane);
-                if (item == 0xFFFFFFFFu) { drained = true; break; }
-                pool_item = item; pool_next = 0;
+                uint32_t item = fetch_item(p, home, qc, lane);
+                if (p.item_cost) {   // wave-level iterations since the previous fetch = what that item cost
+                    if (item_live && lane == 0) p.item_cost[pool_item] = item_work;
+                    item_work = 0; item_live = true;
+                }
 #ifdef RTAMD_EXP_STAMPS
                 {   // with dyn_thresh == 1 a fetch happens only when the previous item is completely done
                     unsigned long long now = __builtin_amdgcn_s_memrealtime();
-                    if (stamp_items && now - stamp_last > stamp_worst) { stamp_worst = now - stamp_last; stamp_worst_item = pool_item; }
-                    stamp_last = now;
+                    if (stamp_items && lane == 0 && p.stamps) {
+                        unsigned long long *o = p.stamps + 1048576ull + 4ull * pool_item;
+                        o[0] = stamp_last; o[1] = now; o[2] = (stamp_inner - snap_inner) | ((stamp_leaf - snap_leaf) << 32); o[3] = ((tm_inner - snap_tmi) >> 4) | (((tm_leaf - snap_tml) >> 4) << 32);
+                    }
+                    if (stamp_items && now - stamp_last > stamp_worst) { stamp_worst = now - stamp_last; stamp_worst_item = pool_item;
+                        w_inner = stamp_inner - snap_inner; w_leaf = stamp_leaf - snap_leaf; w_uniform = stamp_uniform - snap_uniform; w_lanes = stamp_inner_lanes - snap_lanes; }
+                    if (item != 0xFFFFFFFFu) {
+                        stamp_last = now; snap_inner = stamp_inner; snap_leaf = stamp_leaf; snap_uniform = stamp_uniform; snap_lanes = stamp_inner_lanes;
+                        snap_tmi = tm_inner; snap_tml = tm_leaf;
+                        stamp_items++;
+                    }
                 }
-                stamp_items++;
 #endif
+                if (item == 0xFFFFFFFFu) { drained = true; break; }
+                pool_item = item; pool_next = 0;
+                if (prio_level) { __builtin_amdgcn_s_setprio(0); prio_level = 0; }
+                item_work = 0;
+                prio_next = p.prio_thresh ? p.prio_thresh : 0xFFFFFFFFu;
             }
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             const uint32_t avail = 64u - pool_next;
@@ -588,6 +626,9 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
         for (;;) {
             const bool busy = tr.cur != REF_NONE;
             if ((uint32_t)__popcll(__ballot(busy)) < thresh) break;
+#ifdef RTAMD_EXP_STAMPS
+            const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
+#endif
             // while-while with early leaf release: lanes that reached a leaf wait for the
             // others to finish their inner-node steps, but only until `leaf_thresh` lanes
             // are waiting (64 = classic while-while, 1 = if-if).  Per-lane order is
@@ -606,14 +647,29 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                 }
 #endif
                 trav_inner_step<COUNT>(s, tr, st, tid, in, m_in, nbox);
+                item_work += 2;
+            }
+            item_work += 3;
+            if (item_work >= prio_next) {   // the longer a wave has held its item, the sooner the SIMD issues it
+                prio_level++;
+                if (prio_level == 1) __builtin_amdgcn_s_setprio(1);
+                else if (prio_level == 2) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(3);
+                prio_next = prio_level >= 3 ? 0xFFFFFFFFu : prio_next + (p.prio_thresh << prio_level);
             }
             {
                 const bool lf = busy && tr.cur != REF_NONE && !ref_is_inner(tr.cur);
 #ifdef RTAMD_EXP_STAMPS
+                const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
+                tm_inner += tm1 - tm0;
                 const unsigned long long m = __ballot(lf);
                 if (m) { stamp_leaf++; stamp_leaf_lanes += __popcll(m); }
 #endif
                 if (lf) trav_leaf<COUNT>(s, tr, st, tid, ntri);
+#ifdef RTAMD_EXP_STAMPS
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                tm_leaf += __builtin_amdgcn_s_memtime() - tm1;
+#endif
             }
         }
 
@@ -653,10 +709,13 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
     }
 #ifdef RTAMD_EXP_STAMPS
     if (lane == 0 && p.stamps) {
-        unsigned long long *o = p.stamps + 8ull * (blockIdx.x * (BLOCK / 64) + (tid >> 6));
+        unsigned long long *o = p.stamps + 16ull * (blockIdx.x * (BLOCK / 64) + (tid >> 6));
         o[4] = stamp_inner; o[5] = stamp_inner_lanes; o[6] = stamp_leaf | (stamp_uniform << 32); o[7] = stamp_leaf_lanes;
         unsigned long long now = __builtin_amdgcn_s_memrealtime();
-        if (now - stamp_last > stamp_worst) { stamp_worst = now - stamp_last; stamp_worst_item = pool_item; }
+        if (now - stamp_last > stamp_worst) { stamp_worst = now - stamp_last; stamp_worst_item = pool_item;
+            w_inner = stamp_inner - snap_inner; w_leaf = stamp_leaf - snap_leaf; w_uniform = stamp_uniform - snap_uniform; w_lanes = stamp_inner_lanes - snap_lanes; }
+        o[8] = w_inner; o[9] = w_leaf; o[10] = w_uniform; o[11] = w_lanes;
+        o[12] = tm_inner; o[13] = tm_leaf; o[14] = __builtin_amdgcn_s_memtime() - tm_start; o[15] = now - stamp_last;
         o[0] = stamp_t0; o[1] = now; o[2] = stamp_items | (stamp_worst << 32); o[3] = xcc_id() | (stamp_worst_item << 8);
     }
 #endif
@@ -745,6 +804,30 @@ __global__ void k_generate_rays(const float *__restrict__ ipv16, float near_, fl
     float dx, dy, dz;
     gen_primary_dir(m, near_, far_, width, height, px, py, dx, dy, dz);
     dir_out[3 * (size_t)i + 0] = dx; dir_out[3 * (size_t)i + 1] = dy; dir_out[3 * (size_t)i + 2] = dz;
+}
+
+// Next frame's schedule: items ordered by this frame's measured cost, longest first
+// (64 linear cost classes; order inside a class is arbitrary).  One workgroup: n is a
+// few 10^4..10^5 and the kernel runs once per frame behind the render kernel.
+__global__ void __launch_bounds__(1024) k_reorder(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ order) {
+    __shared__ uint32_t s_max, s_hist[64], s_base[64];
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_max = 1;
+    if (tid < 64) s_hist[tid] = 0;
+    __syncthreads();
+    uint32_t m = 0;
+    for (uint32_t i = tid; i < n; i += 1024) m = max(m, cost[i]);
+    atomicMax(&s_max, m);
+    __syncthreads();
+    const uint32_t quantum = s_max / 64u + 1u;
+    for (uint32_t i = tid; i < n; i += 1024) atomicAdd(&s_hist[min(63u, cost[i] / quantum)], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int b = 63; b >= 0; b--) { s_base[b] = acc; acc += s_hist[b]; }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 1024) order[atomicAdd(&s_base[min(63u, cost[i] / quantum)], 1u)] = i;
 }
 
 // Root side of the gather: rank-major tile blocks -> scan-line frame.

@@ -44,6 +44,10 @@ struct rtamd_context {
     int32_t tex_w[2] = {1, 1}, tex_h[2] = {1, 1};
     DevBuf white;
     DevBuf queues;
+    // LPT schedule (k_persistent): per-item cost measured by frame f orders the items of frame f+1
+    DevBuf item_cost, item_order;
+    uint32_t order_items[2] = {0, 0};   // n_items the schedule of mode [fused, trace] is valid for (0 = none yet)
+    bool adaptive_order = false;
     DevBuf spill;  // traversal-stack overflow of the persistent kernel, one slice per resident wave
     DevBuf ipv;  // 16 floats for k_generate_rays
 #ifdef RTAMD_EXP_STAMPS
@@ -55,7 +59,9 @@ struct rtamd_context {
     // re-fill (1), incoherent ray streams with re-fill below 32 busy lanes; leaves are
     // released when 4 lanes wait
     uint32_t dyn_thresh_fused = 1, dyn_thresh_trace = 32;
-    uint32_t leaf_thresh = 4;
+    uint32_t leaf_thresh = 8;
+    uint32_t prio_thresh = 0;
+    uint32_t queue_stride = 64, chunk = 1;
     uint32_t n_queues = 8;
 };
 
@@ -130,13 +136,28 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     p.n_queues = ctx->n_queues;
     p.dyn_thresh = mode == MODE_FUSED ? ctx->dyn_thresh_fused : ctx->dyn_thresh_trace;
     p.leaf_thresh = ctx->leaf_thresh;
+    p.prio_thresh = ctx->prio_thresh;
+    p.queue_stride = ctx->queue_stride; p.chunk = ctx->chunk;
     p.spill = (uint32_t *)ctx->spill.p;
+    p.item_cost = nullptr; p.item_order = nullptr;
+    if (ctx->variant == 0 && ctx->adaptive_order) {
+        // one cost / order array pair per mode, sized for the largest launch seen so far
+        const size_t need = (size_t)p.n_items * sizeof(uint32_t);
+        if (ctx->item_cost.bytes < 2 * need) {
+            int rc;
+            if ((rc = dev_alloc(ctx, ctx->item_cost, 2 * need)) || (rc = dev_alloc(ctx, ctx->item_order, 2 * need))) return rc;
+            ctx->order_items[0] = ctx->order_items[1] = 0;
+        }
+        const size_t half = ctx->item_cost.bytes / 2 / sizeof(uint32_t);
+        p.item_cost = (uint32_t *)ctx->item_cost.p + (size_t)mode * half;
+        if (ctx->order_items[mode] == p.n_items) p.item_order = (const uint32_t *)ctx->item_order.p + (size_t)mode * half;
+    }
 #ifdef RTAMD_EXP_STAMPS
     p.stamps = (unsigned long long *)ctx->stamps.p;
 #endif
     hipStream_t st = ctx->stream;
     const SceneDev &s = ctx->sdev;
-    if (ctx->variant == 0) HIP_TRY(ctx, hipMemsetAsync(ctx->queues.p, 0, ctx->queues.bytes, st));
+    if (ctx->variant == 0) HIP_TRY(ctx, hipMemsetAsync(ctx->queues.p, 0, (size_t)ctx->n_queues * ctx->queue_stride * sizeof(uint32_t), st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_start, st));
     if (ctx->variant == 0) {
         int per_cu = ctx->persistent_blocks_per_cu[mode * 2 + (count ? 1 : 0)];
@@ -164,6 +185,13 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, st));
     ctx->ev_valid = true;
+    if (p.item_cost) {
+        const size_t half = ctx->item_cost.bytes / 2 / sizeof(uint32_t);
+        hipLaunchKernelGGL(k_reorder, dim3(1), dim3(1024), 0, st, (const uint32_t *)p.item_cost, p.n_items,
+                           (uint32_t *)ctx->item_order.p + (size_t)mode * half);
+        HIP_TRY(ctx, hipGetLastError());
+        ctx->order_items[mode] = p.n_items;
+    }
     return RTAMD_OK;
 }
 
@@ -239,12 +267,12 @@ int rtamd_context_create(int device_ordinal, rtamd_context **out_ctx) {
         if ((rc = dev_alloc(ctx, ctx->spill, waves * SPILL_STACK_ENTRIES * 64 * sizeof(uint32_t)))) return bail(rc);
     }
 #ifdef RTAMD_EXP_STAMPS
-    if ((rc = dev_alloc(ctx, ctx->stamps, 65536 * 64))) return bail(rc);
+    if ((rc = dev_alloc(ctx, ctx->stamps, 65536 * 128 + 65536 * 32))) return bail(rc);
     (void)hipMemset(ctx->stamps.p, 0, ctx->stamps.bytes);
 #endif
     const uint32_t white = 0xFFFFFFFFu;
     if ((rc = dev_upload(ctx, ctx->white, &white, 4))) return bail(rc);
-    if ((rc = dev_alloc(ctx, ctx->queues, 8 * 64))) return bail(rc);
+    if ((rc = dev_alloc(ctx, ctx->queues, 32 * 16384))) return bail(rc);
     if ((rc = dev_alloc(ctx, ctx->ipv, 64))) return bail(rc);
     *out_ctx = ctx;
     return RTAMD_OK;
@@ -256,7 +284,7 @@ void rtamd_context_destroy(rtamd_context *ctx) {
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     ctx->nodes.release(); ctx->tris.release(); ctx->big.release(); ctx->tri_idx.release();
     ctx->normals.release(); ctx->texcoords.release(); ctx->tex[0].release(); ctx->tex[1].release();
-    ctx->white.release(); ctx->queues.release(); ctx->spill.release(); ctx->ipv.release();
+    ctx->white.release(); ctx->queues.release(); ctx->spill.release(); ctx->item_cost.release(); ctx->item_order.release(); ctx->ipv.release();
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -295,8 +323,20 @@ int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value) {
     } else if (!std::strcmp(name, "leaf_thresh")) {
         if (value < 1 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "leaf_thresh must be 1..64");
         ctx->leaf_thresh = (uint32_t)value;
+    } else if (!std::strcmp(name, "prio_thresh")) {
+        if (value < 0 || value > (1 << 24)) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "prio_thresh must be 0..2^24");
+        ctx->prio_thresh = (uint32_t)value;
+    } else if (!std::strcmp(name, "queue_stride")) {
+        if (value < 1 || value > 4096) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "queue_stride must be 1..4096 words");
+        ctx->queue_stride = (uint32_t)value;
+    } else if (!std::strcmp(name, "chunk")) {
+        if (value < 1 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "chunk must be 1..64");
+        ctx->chunk = (uint32_t)value;
+    } else if (!std::strcmp(name, "adaptive_order")) {
+        ctx->adaptive_order = value != 0;
+        ctx->order_items[0] = ctx->order_items[1] = 0;
     } else if (!std::strcmp(name, "num_queues")) {
-        if (value < 1 || value > 8) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "num_queues must be 1..8");
+        if (value < 1 || value > 32) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "num_queues must be 1..32");
         ctx->n_queues = (uint32_t)value;
     } else if (!std::strcmp(name, "kernel_variant")) {
         return rtamd_set_kernel_variant(ctx, (int)value);
@@ -618,10 +658,16 @@ int rtamd_get_scene_info(const rtamd_context *ctx, rtamd_scene_info *info) {
 
 #ifdef RTAMD_EXP_STAMPS
 /* diagnostic build only (not declared in include/rtamd.h) */
+int rtamd_exp_read_items(rtamd_context *ctx, unsigned long long *out, uint32_t items) {
+    if (!ctx || !out || items > 65536) return RTAMD_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, (unsigned long long *)ctx->stamps.p + 1048576, (size_t)items * 32, hipMemcpyDeviceToHost));
+    return RTAMD_OK;
+}
 int rtamd_exp_read_stamps(rtamd_context *ctx, unsigned long long *out, uint32_t waves) {
     if (!ctx || !out || waves > 65536) return RTAMD_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(out, ctx->stamps.p, (size_t)waves * 64, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->stamps.p, (size_t)waves * 128, hipMemcpyDeviceToHost));
     return RTAMD_OK;
 }
 #endif
