@@ -214,6 +214,11 @@ int rtamd_set_kernel_variant(rtamd_context *ctx, int variant);
  *                       current item has cost this many loop-iteration units (again at x3, x7);
  *  "adaptive_order" 0/1 schedule a frame's items by the cost counted for them in the previous
  *                       launch of the same size, longest first (default 0: measured slower);
+ *  "shadow_anyhit" 0/1  fused shader only (default 1): a shadow ray stops at the first leaf that
+ *                       leaves its t below the 1000 limit.  The reference traverses on
+ *                       (ray_trace_and_shade.frag:213-219) but consumes only `shadow_t < 1000`, which
+ *                       cannot change once true, so every output is identical; only the optional
+ *                       per-pixel test counters are smaller.  0 = traverse to the end (counter parity);
  *  "kernel_variant"     as rtamd_set_kernel_variant. */
 int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value);
 

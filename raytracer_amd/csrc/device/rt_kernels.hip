@@ -81,6 +81,7 @@ struct JobParams {
     uint32_t n_queues;
     uint32_t dyn_thresh;
     uint32_t leaf_thresh;
+    uint32_t shadow_anyhit;       // fused mode: shadow rays stop at the first leaf that leaves t < T_HIT_LIMIT
     uint32_t queue_stride;        // u32 words between queue counters
     uint32_t chunk;               // schedule positions taken per atomic
     uint32_t prio_thresh;         // 0 = off; else a wave raises its issue priority when its item has cost this much work (x2, x4)
@@ -302,8 +303,12 @@ __device__ __forceinline__ void trav_inner_step(const SceneDev &s, Trav &tr, Sta
 }
 
 // One leaf visit (:122-136): all triangles in ascending order, then pop.
+// `occlusion`: this lane's ray is a shadow ray whose caller consumes only the predicate
+// `t < T_HIT_LIMIT` (:219); once a leaf leaves t below the limit the rest of the traversal
+// can only lower t further, so the lane stops there.  The predicate, hence every output,
+// is the one the full traversal gives; only the box/triangle test counters differ.
 template <bool COUNT, class Stack>
-__device__ __forceinline__ void trav_leaf(const SceneDev &s, Trav &tr, const Stack &st, uint32_t tid, uint32_t &ntri) {
+__device__ __forceinline__ void trav_leaf(const SceneDev &s, Trav &tr, const Stack &st, uint32_t tid, uint32_t &ntri, bool occlusion = false) {
     uint32_t ref = tr.cur;
     uint32_t count = (ref >> REF_COUNT_SHIFT) & 15u;
     uint32_t first = ref & REF_FIRST_MASK;
@@ -313,6 +318,7 @@ __device__ __forceinline__ void trav_leaf(const SceneDev &s, Trav &tr, const Sta
     }
     if (COUNT) ntri += count;
     for (uint32_t i = first; i < first + count; i++) tri_test(tr.ray, s.tris, i, tr.t, tr.idx, tr.u, tr.v);
+    if (occlusion && tr.t < T_HIT_LIMIT) { tr.cur = REF_NONE; return; }
     tr.cur = tr.sp ? stack_pop(st, tid, tr.sp) : REF_NONE;
 }
 
@@ -320,10 +326,10 @@ __device__ __forceinline__ bool ref_is_inner(uint32_t ref) { return (ref & REF_L
 
 // Run this lane's traversal to completion (static kernel).
 template <bool COUNT, class Stack>
-__device__ __forceinline__ void trav_run(const SceneDev &s, Trav &tr, Stack &st, uint32_t tid, uint32_t &nbox, uint32_t &ntri) {
+__device__ __forceinline__ void trav_run(const SceneDev &s, Trav &tr, Stack &st, uint32_t tid, uint32_t &nbox, uint32_t &ntri, bool occlusion = false) {
     while (tr.cur != REF_NONE) {
         while (ref_is_inner(tr.cur)) trav_inner<COUNT>(s, tr, st, tid, nbox);
-        if (tr.cur != REF_NONE) trav_leaf<COUNT>(s, tr, st, tid, ntri);
+        if (tr.cur != REF_NONE) trav_leaf<COUNT>(s, tr, st, tid, ntri, occlusion);
     }
 }
 
@@ -665,7 +671,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                 const unsigned long long m = __ballot(lf);
                 if (m) { stamp_leaf++; stamp_leaf_lanes += __popcll(m); }
 #endif
-                if (lf) trav_leaf<COUNT>(s, tr, st, tid, ntri);
+                if (lf) trav_leaf<COUNT>(s, tr, st, tid, ntri, MODE == MODE_FUSED && p.shadow_anyhit && phase == PH_SHADOW);
 #ifdef RTAMD_EXP_STAMPS
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 tm_leaf += __builtin_amdgcn_s_memtime() - tm1;
@@ -779,7 +785,7 @@ __global__ void __launch_bounds__(BLOCK) k_static(const SceneDev s, const JobPar
         shade_primary(s, p, tr, col_shadow, col_lit, sray);
         tr.ray = sray;
         trav_begin<COUNT>(s, tr, T_PRIMARY0, nbox);
-        trav_run<COUNT>(s, tr, st, tid, nbox, ntri);
+        trav_run<COUNT>(s, tr, st, tid, nbox, ntri, p.shadow_anyhit != 0);
         c = (tr.t < T_HIT_LIMIT) ? col_shadow : col_lit;
         id = prim_idx;
     } else {

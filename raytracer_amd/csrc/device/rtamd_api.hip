@@ -61,6 +61,7 @@ struct rtamd_context {
     uint32_t dyn_thresh_fused = 1, dyn_thresh_trace = 32;
     uint32_t leaf_thresh = 8;
     uint32_t prio_thresh = 0;
+    bool shadow_anyhit = true;
     uint32_t queue_stride = 64, chunk = 1;
     uint32_t n_queues = 8;
 };
@@ -137,6 +138,7 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     p.dyn_thresh = mode == MODE_FUSED ? ctx->dyn_thresh_fused : ctx->dyn_thresh_trace;
     p.leaf_thresh = ctx->leaf_thresh;
     p.prio_thresh = ctx->prio_thresh;
+    p.shadow_anyhit = ctx->shadow_anyhit ? 1u : 0u;
     p.queue_stride = ctx->queue_stride; p.chunk = ctx->chunk;
     p.spill = (uint32_t *)ctx->spill.p;
     p.item_cost = nullptr; p.item_order = nullptr;
@@ -332,6 +334,8 @@ int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value) {
     } else if (!std::strcmp(name, "chunk")) {
         if (value < 1 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "chunk must be 1..64");
         ctx->chunk = (uint32_t)value;
+    } else if (!std::strcmp(name, "shadow_anyhit")) {
+        ctx->shadow_anyhit = value != 0;
     } else if (!std::strcmp(name, "adaptive_order")) {
         ctx->adaptive_order = value != 0;
         ctx->order_items[0] = ctx->order_items[1] = 0;

@@ -144,10 +144,17 @@ def test_full_size_atrium_properties(tracer, oracle_a, atrium):
     tracer.upload_texture(0, tex[0]); tracer.upload_texture(1, tex[1])
     inv = camera.inv_proj_view()
     ref = None
+    defaults = {"kernel_variant": 0, "dyn_thresh": 1, "leaf_thresh": 8, "num_queues": 8, "queue_stride": 64, "chunk": 1,
+                "prio_thresh": 0, "adaptive_order": 0, "shadow_anyhit": 1}
     try:
+        tracer.set_option("shadow_anyhit", 0)   # reference-length shadow traversals: counters comparable with the oracle
+        full = tracer.render(W, H, camera=(inv, camera.position), has_tex_coords=1, has_normals=1, want=("rgba", "hit_id", "hit_t", "counts"))
+        tracer.set_option("shadow_anyhit", 1)
         for opts in ({"kernel_variant": 1}, {"kernel_variant": 0, "dyn_thresh": 1, "leaf_thresh": 4, "num_queues": 8},
-                     {"kernel_variant": 0, "dyn_thresh": 40, "leaf_thresh": 64, "num_queues": 1},
-                     {"kernel_variant": 0, "dyn_thresh": 64, "leaf_thresh": 1, "num_queues": 3}):
+                     {"kernel_variant": 0, "dyn_thresh": 40, "leaf_thresh": 64, "num_queues": 1, "queue_stride": 16, "chunk": 3},
+                     {"kernel_variant": 0, "dyn_thresh": 64, "leaf_thresh": 1, "num_queues": 3, "prio_thresh": 50},
+                     {"kernel_variant": 0, "dyn_thresh": 1, "leaf_thresh": 8, "num_queues": 16, "adaptive_order": 1, "chunk": 1, "prio_thresh": 0},
+                     {"kernel_variant": 0, "adaptive_order": 1}):
             for k, v in opts.items():
                 tracer.set_option(k, v)
             r = tracer.render(W, H, camera=(inv, camera.position), has_tex_coords=1, has_normals=1, want=("rgba", "hit_id", "hit_t", "counts"))
@@ -157,9 +164,12 @@ def test_full_size_atrium_properties(tracer, oracle_a, atrium):
                 for key in ("rgba", "hit_id", "hit_t", "counts"):
                     assert np.array_equal(ref[key].view(np.uint32), r[key].view(np.uint32)), (opts, key)
     finally:
-        for k, v in {"kernel_variant": 0, "dyn_thresh": 1, "leaf_thresh": 4, "num_queues": 8}.items():
+        for k, v in defaults.items():
             tracer.set_option(k, v)
-        tracer.set_option("dyn_thresh", 1)
+    for key in ("rgba", "hit_id", "hit_t"):   # stopping shadow rays at the first occluder changes no output
+        assert np.array_equal(ref[key].view(np.uint32), full[key].view(np.uint32)), key
+    assert np.all(ref["counts"] <= full["counts"]) and ref["counts"].sum() < full["counts"].sum()
+    ref = full
     hit = ref["hit_id"] != 0xFFFFFFFF
     assert 0.9 < hit.mean() < 0.99 and np.all(ref["rgba"][:, 3] == 1)
     dirs, orgs = camera.primary_rays(W, H)
