@@ -11,6 +11,12 @@ frame is split into interleaved 32x32 tiles (scene replicated), every rank
 renders its tiles, one RCCL gather brings them to rank 0, which assembles the
 scan-line frame — all inside the timed step.
 
+Frames in flight (default 2): consecutive frames are issued on alternating HIP
+streams (the library keeps per-stream launch scratch, include/rtamd.h), each into
+its own output buffer, so the slow tail of frame k overlaps the start of frame
+k+1 — how a real-time renderer submits frames.  All K frames complete inside the
+timed region.  `--frames-in-flight 1` gives the strictly serial number.
+
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
 """
 import argparse
@@ -62,6 +68,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="atrium_1080p")
     ap.add_argument("--variant", type=int, default=0, help="0 persistent (default), 1 static A/B baseline")
+    ap.add_argument("--frames-in-flight", type=int, default=2, help="frames issued on alternating streams (1 = serial)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -76,10 +83,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # Rehearsal on a one-GPU box (not a measurement): RTAMD_BENCH_REHEARSE=1 puts every rank on
+    # cuda:0 and moves the gather through gloo/host memory, to exercise the N>1 stream logic.
+    rehearse = world > 1 and os.environ.get("RTAMD_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     t0 = time.time()
     model, camera, W, H, tex = build_workload(args.workload)
@@ -107,23 +122,68 @@ def main():
 
     per_rank_tiles = tracer.tiles_per_rank(W, H, world)
     n_local_out = n_px if world == 1 else per_rank_tiles * TILE_PIXELS
-    d_rgba = torch.zeros((n_local_out, 4), dtype=torch.float32, device=dev)
-    gathered = None
+    F = max(1, min(4, args.frames_in_flight))
+    # frame k renders on render_streams[k % F] into rgba[k % F]; gather + assembly stay on `stream`
+    render_streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(F - 1)]
+    rgba = [torch.zeros((n_local_out, 4), dtype=torch.float32, device=dev) for _ in range(F)]
+    consumed = [torch.cuda.Event() for _ in range(F)]   # frame in rgba[f] has been gathered
+    d_rgba = rgba[0]
+    if F == 2:
+        # HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES = 4 here) and two streams that
+        # share one cannot overlap: try a handful of partner streams and keep the one that overlaps best.
+        def pair_ms(partner, frames=16):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(frames):
+                tracer.set_stream((stream, partner)[k % 2].cuda_stream)
+                tracer.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=has_tc, has_normals=has_n,
+                                     tile_rank=rank, tile_world=world, rgba_ptr=rgba[k % 2].data_ptr())
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / frames
+        candidates = [render_streams[1]] + [torch.cuda.Stream(device=dev) for _ in range(3)]
+        for c in candidates:
+            pair_ms(c, 4)   # first use of a stream creates its queue
+        render_streams[1] = min(candidates, key=pair_ms)
+        tracer.set_stream(stream.cuda_stream)
     frame = None
     if world > 1 and rank == 0:
-        gathered = [torch.empty_like(d_rgba) for _ in range(world)]
         gathered_flat = torch.empty((world * n_local_out, 4), dtype=torch.float32, device=dev)
         frame = torch.empty((n_px, 4), dtype=torch.float32, device=dev)
+    launch_events = []
 
-    def step():
+    def step(k, timed=False):
+        f = k % F
+        rs = render_streams[f]
+        if world > 1 and F > 1 and k >= F:
+            rs.wait_event(consumed[f])          # rgba[f] is free again once frame k-F has been gathered
+        tracer.set_stream(rs.cuda_stream)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(rs)
         tracer.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=has_tc, has_normals=has_n,
-                             tile_rank=rank, tile_world=world, rgba_ptr=d_rgba.data_ptr())
+                             tile_rank=rank, tile_world=world, rgba_ptr=rgba[f].data_ptr())
+        if timed:
+            e1.record(rs)
+            launch_events.append((e0, e1))
         if world > 1:
-            if rank == 0:
-                dist.gather(d_rgba, gather_list=list(gathered_flat.view(world, n_local_out, 4).unbind(0)), dst=0)
-                tracer.assemble_tiles_device(gathered_flat.data_ptr(), W, H, world, 4, frame.data_ptr())
+            if F > 1:
+                stream.wait_stream(rs)
+            if rehearse:
+                stream.synchronize()
+                mine = rgba[f].cpu()
+                parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+                dist.gather(mine, gather_list=parts, dst=0)
+                if rank == 0:
+                    gathered_flat.copy_(torch.cat(parts))
+            elif rank == 0:
+                dist.gather(rgba[f], gather_list=list(gathered_flat.view(world, n_local_out, 4).unbind(0)), dst=0)
             else:
-                dist.gather(d_rgba, dst=0)
+                dist.gather(rgba[f], dst=0)
+            if rank == 0:
+                tracer.set_stream(stream.cuda_stream)
+                tracer.assemble_tiles_device(gathered_flat.data_ptr(), W, H, world, 4, frame.data_ptr())
+            if F > 1:
+                consumed[f].record(stream)
 
     # ---- untimed: per-pixel counters of the whole frame (rank-local share) for the roofline
     d_counts = torch.zeros((n_local_out, 2), dtype=torch.int32, device=dev)
@@ -152,8 +212,10 @@ def main():
     rays_per_frame = n_primary_all + n_shadow_all
 
     # ---- warmup + timed region
-    for _ in range(args.warmup):
-        step()
+    tracer.set_stream(stream.cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(args.warmup):
+        step(k)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -161,8 +223,10 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t_start = time.perf_counter()
     ev0.record(stream)
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k, timed=True)
+    for rs in render_streams:
+        stream.wait_stream(rs)
     ev1.record(stream)
     torch.cuda.synchronize()
     if world > 1:
@@ -175,18 +239,23 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed, ev_ms = float(tt[0]), float(tt[1])
 
-    # ---- kernel-only duration of the dominant kernel (HIP events inside the library, rank 0)
-    kms = []
-    for _ in range(min(args.steps, 50)):
-        tracer.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=has_tc, has_normals=has_n,
-                             tile_rank=rank, tile_world=world, rgba_ptr=d_rgba.data_ptr())
-        kms.append(tracer.last_kernel_ms())
-    kernel_ms = float(np.mean(kms))
+    # ---- duration of the dominant kernel's launches: HIP events on the launch stream around every
+    # timed launch (with frames in flight the launches overlap, so this exceeds ms_per_step)
+    kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in launch_events]))
+    tracer.set_stream(stream.cuda_stream)
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
+
+    frame_check = None
+    if world > 1:
+        # untimed: the assembled frame of the last step must equal this rank rendering the whole frame alone
+        full = torch.zeros((n_px, 4), dtype=torch.float32, device=dev)
+        tracer.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=has_tc, has_normals=has_n, rgba_ptr=full.data_ptr())
+        torch.cuda.synchronize()
+        frame_check = bool(torch.equal(full.view(torch.int32), frame.view(torch.int32)))
 
     ms_per_step = elapsed * 1e3 / args.steps
     value = rays_per_frame * args.steps / elapsed / 1e6
@@ -197,8 +266,9 @@ def main():
     shaded_extra = (36 if has_n else 0) + (24 if has_tc else 0) + 16 + 16
     alg_bytes = 36 * n_box + 52 * n_tri + 24 * (n_primary + n_shadow) + 16 * n_primary + shaded_extra * n_shadow
     alg_ops = 25 * n_box + 60 * n_tri + 150 * n_shadow
-    launch_ms = ev_ms / args.steps if world == 1 else kernel_ms
+    launch_ms = kernel_ms
     achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+    job_ms = ev_ms / args.steps
     out = {
         "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -208,11 +278,16 @@ def main():
                                f"{W}x{H}, 1 spp, primary + sun shadow ray + shading (fused ray_trace_and_shade semantics)",
                    "rays_per_frame": rays_per_frame, "primary_rays": n_primary_all, "shadow_rays": n_shadow_all,
                    "parallelism": f"tiles{world}" if world > 1 else "single", "kernel_variant": args.variant,
+                   "frames_in_flight": F, "shadow_rays_stop_at_first_occluder": True,
+                   **({"assembled_frame_equals_single_gpu_frame": frame_check} if frame_check is not None else {}),
+                   **({"REHEARSAL_not_a_measurement": "all ranks on cuda:0, gloo gather through host memory"} if rehearse else {}),
                    "bvh_build_s": round(build_s, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                      "kernel": "k_persistent<fused>" if args.variant == 0 else "k_static<fused>",
-                     "launch_ms": round(launch_ms, 5), "kernel_ms_hip_events": round(kernel_ms, 5),
+                     "launch_ms": round(launch_ms, 5), "launches_overlap": F > 1,
+                     "stream_ms_per_step_hip_events": round(job_ms, 5),
+                     "achieved_per_step": round(alg_bytes / (job_ms * 1e-3) / 1e9, 2),
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "aabb_tests_per_ray": round(n_box / max(1, n_primary + n_shadow), 2),
                      "tri_tests_per_ray": round(n_tri / max(1, n_primary + n_shadow), 2),

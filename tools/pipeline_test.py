@@ -23,13 +23,18 @@ d_org = torch.tensor(np.asarray(camera.position, np.float32), device=dev).repeat
 torch.cuda.synchronize()
 K = 300
 has_tc, has_n = model.has_tex_coords(), model.has_normals()
-for S in (1, 2, 3, 4, 1, 2, 3, 4):
+for S, EV in ((1, 0), (2, 0), (2, 1), (2, 2), (2, 0), (2, 1), (2, 2)):
     for rep in range(2):
+        evs = []
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for k in range(K):
             tr.set_stream(streams[k % S].cuda_stream)
+            if EV:
+                e0 = torch.cuda.Event(enable_timing=(EV == 1)); e1 = torch.cuda.Event(enable_timing=(EV == 1)); e0.record(streams[k % S])
             tr.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=has_tc, has_normals=has_n, rgba_ptr=bufs[k % S].data_ptr())
+            if EV:
+                e1.record(streams[k % S]); evs.append((e0, e1))
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"frames in flight {S}: {dt / K * 1e3:.4f} ms per frame, last kernel {tr.last_kernel_ms():.4f} ms", flush=True)
+    print(f"frames in flight {S}, torch events {EV}: {dt / K * 1e3:.4f} ms per frame, last kernel {tr.last_kernel_ms():.4f} ms", flush=True)
 for b in bufs[1:]:
     assert torch.equal(bufs[0], b)
