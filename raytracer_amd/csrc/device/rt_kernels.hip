@@ -26,6 +26,7 @@
 // in LDS ([entry][thread], conflict-free for ds_read/write_b32) and spill to
 // scratch beyond LDS_STACK_ENTRIES.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "rt_layout.h"
@@ -37,10 +38,12 @@ constexpr float EPSILON = 0.000001f;   // :11
 constexpr float T_PRIMARY0 = 1000000.0f;  // :199,211
 constexpr float T_HIT_LIMIT = 1000.0f;    // :206,219
 constexpr int BLOCK = 256;
-// k_persistent is latency-bound: occupancy matters (32 -> 20 waves per CU costs 13 %),
-// but forcing 8 waves per SIMD (<= 64 VGPRs) spills into the loop; 6 (<= 80) measured best.
+// k_persistent is latency-bound: occupancy matters.  8 waves per SIMD (<= 64 VGPRs; the
+// register spills this forces sit in the shading code and in the rare stack-overflow
+// branches, not in the visit loop) measured 4 % faster than 6 (<= 80 VGPRs) with frames
+// in flight on coherent rays, 4 % slower on shuffled (incoherent) rays; 5 is 4 % slower.
 #ifndef RTAMD_WAVES_PER_EU
-#define RTAMD_WAVES_PER_EU 6
+#define RTAMD_WAVES_PER_EU 8
 #endif
 #define RTAMD_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(RTAMD_WAVES_PER_EU, RTAMD_WAVES_PER_EU)))
 
@@ -232,6 +235,23 @@ __device__ __forceinline__ bool slab(const Ray &r, float minx, float miny, float
     return hi >= lo && lo < t && hi > 0.0f;
 }
 
+// Slab test for a ray whose direction octant is known: OCT bit k set = component k is
+// negative; all three inverses finite and non-zero.  (lo - o) * r <= (hi - o) * r holds in
+// float for r > 0 (subtraction and multiplication by a positive number are monotonic) and
+// the reverse for r < 0, so min(t1,t2) / max(t1,t2) of `slab` are known operands, bit for
+// bit, and the six min/max per box disappear.  OCT < 0: the general test.
+template <int OCT>
+__device__ __forceinline__ bool slab_sel(const Ray &r, float minx, float miny, float minz, float maxx, float maxy, float maxz, float t, float &tmin) {
+    if (OCT < 0) return slab(r, minx, miny, minz, maxx, maxy, maxz, t, tmin);
+    const float nx = (OCT & 1) ? maxx : minx, fx = (OCT & 1) ? minx : maxx;
+    const float ny = (OCT & 2) ? maxy : miny, fy = (OCT & 2) ? miny : maxy;
+    const float nz = (OCT & 4) ? maxz : minz, fz = (OCT & 4) ? minz : maxz;
+    float lo = fmaxf(fmaxf((nx - r.ox) * r.rx, (ny - r.oy) * r.ry), (nz - r.oz) * r.rz);
+    float hi = fminf(fminf((fx - r.ox) * r.rx, (fy - r.oy) * r.ry), (fz - r.oz) * r.rz);
+    tmin = lo;
+    return hi >= lo && lo < t && hi > 0.0f;
+}
+
 // One inner-node visit (:138-148): test both children with the current t, descend
 // into the nearer hit child, defer the other.  With dist = hit ? tmin : 1e30 the
 // shader's `dist0 < dist1` is  hit0 && (!hit1 || tmin0 < tmin1)  (a hit has
@@ -265,7 +285,7 @@ __device__ __forceinline__ uint32_t touch_ref(const SceneDev &s, uint32_t ref) {
 }
 
 // Vector fetch: every lane loads its own 64-byte record (4 x global_load_dwordx4).
-template <bool COUNT, class Stack>
+template <bool COUNT, int OCT = -1, class Stack>
 __device__ __forceinline__ void trav_inner(const SceneDev &s, Trav &tr, Stack &st, uint32_t tid, uint32_t &nbox) {
     const float4 *np = reinterpret_cast<const float4 *>(&s.nodes[tr.cur]);
     const float4 q0 = np[0], q1 = np[1], q2 = np[2];
@@ -280,8 +300,8 @@ __device__ __forceinline__ void trav_inner(const SceneDev &s, Trav &tr, Stack &s
 #endif
     if (COUNT) nbox += 2;
     float tmin0, tmin1;
-    const bool hit0 = slab(tr.ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tr.t, tmin0);
-    const bool hit1 = slab(tr.ray, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr.t, tmin1);
+    const bool hit0 = slab_sel<OCT>(tr.ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tr.t, tmin0);
+    const bool hit1 = slab_sel<OCT>(tr.ray, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr.t, tmin1);
     trav_select(tr, st, tid, hit0, hit1, tmin0, tmin1, refs.x, refs.y);
 }
 
@@ -290,7 +310,7 @@ __device__ __forceinline__ void trav_inner(const SceneDev &s, Trav &tr, Stack &s
 // is read once through the scalar cache (s_load_dwordx16) into SGPRs, which the slab
 // arithmetic takes as scalar operands: no texture-address/L1 traffic, no VGPRs.
 typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
-template <bool COUNT, class Stack>
+template <bool COUNT, int OCT = -1, class Stack>
 __device__ __forceinline__ void trav_inner_uniform(const SceneDev &s, Trav &tr, Stack &st, uint32_t tid, uint32_t node, uint32_t &nbox) {
     const_u32_ptr q = (const_u32_ptr)(uintptr_t)(s.nodes + node);
     uint32_t w[14];
@@ -298,20 +318,20 @@ __device__ __forceinline__ void trav_inner_uniform(const SceneDev &s, Trav &tr, 
     for (int k = 0; k < 14; k++) w[k] = q[k];
     if (COUNT) nbox += 2;
     float tmin0, tmin1;
-    const bool hit0 = slab(tr.ray, __uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]),
-                           __uint_as_float(w[4]), __uint_as_float(w[5]), tr.t, tmin0);
-    const bool hit1 = slab(tr.ray, __uint_as_float(w[6]), __uint_as_float(w[7]), __uint_as_float(w[8]), __uint_as_float(w[9]),
-                           __uint_as_float(w[10]), __uint_as_float(w[11]), tr.t, tmin1);
+    const bool hit0 = slab_sel<OCT>(tr.ray, __uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]),
+                                    __uint_as_float(w[4]), __uint_as_float(w[5]), tr.t, tmin0);
+    const bool hit1 = slab_sel<OCT>(tr.ray, __uint_as_float(w[6]), __uint_as_float(w[7]), __uint_as_float(w[8]), __uint_as_float(w[9]),
+                                    __uint_as_float(w[10]), __uint_as_float(w[11]), tr.t, tmin1);
     trav_select(tr, st, tid, hit0, hit1, tmin0, tmin1, w[12], w[13]);
 }
 
 // One inner step for the lanes in `in` (ballot `m_in`): scalar path when they agree.
-template <bool COUNT, class Stack>
+template <bool COUNT, int OCT = -1, class Stack>
 __device__ __forceinline__ void trav_inner_step(const SceneDev &s, Trav &tr, Stack &st, uint32_t tid, bool in, unsigned long long m_in, uint32_t &nbox) {
     const uint32_t c0 = __builtin_amdgcn_readlane(tr.cur, (int)__builtin_ctzll(m_in));   // node of the first lane in m_in
     const bool uniform = __builtin_amdgcn_ballot_w64(tr.cur == c0) == m_in;   // c0 is an inner ref: equal lanes are in m_in
-    if (uniform) { if (in) trav_inner_uniform<COUNT>(s, tr, st, tid, c0, nbox); }
-    else if (in) trav_inner<COUNT>(s, tr, st, tid, nbox);
+    if (uniform) { if (in) trav_inner_uniform<COUNT, OCT>(s, tr, st, tid, c0, nbox); }
+    else if (in) trav_inner<COUNT, OCT>(s, tr, st, tid, nbox);
 }
 
 // One leaf visit (:122-136): all triangles in ascending order, then pop.
@@ -520,8 +540,15 @@ __device__ __forceinline__ uint32_t fetch_item(const JobParams &p, uint32_t home
     }
 }
 
-enum : uint32_t { PH_IDLE = 0, PH_PRIMARY = 1, PH_SHADOW = 2 };
+enum : uint32_t { PH_IDLE = 0, PH_PRIMARY = 1, PH_SHADOW = 2 };   // bits 2..5: (8 | direction octant) << 2 when the octant test applies
 enum : int { MODE_FUSED = 0, MODE_TRACE = 1 };
+__device__ __forceinline__ uint32_t ray_pos_flag(const Ray &r) {
+    // octant code for slab_sel<OCT>: all three inverse components finite and non-zero
+    const float inf = __builtin_inff();
+    const bool ok = fabsf(r.rx) < inf && fabsf(r.ry) < inf && fabsf(r.rz) < inf && r.rx != 0.0f && r.ry != 0.0f && r.rz != 0.0f;
+    const uint32_t oct = (r.rx < 0.0f ? 1u : 0u) | (r.ry < 0.0f ? 2u : 0u) | (r.rz < 0.0f ? 4u : 0u);
+    return ok ? ((8u | oct) << 2) : 0u;
+}
 
 // ---------------------------------------------------------------------------
 // k_persistent — production kernel
@@ -614,7 +641,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                         out_index = pr.out_index;
                         nbox = 0; ntri = 0;
                         trav_begin<COUNT>(s, tr, T_PRIMARY0, st.sp_init(tid), nbox);
-                        phase = PH_PRIMARY;
+                        phase = PH_PRIMARY | ray_pos_flag(tr.ray);
                     }
                 } else {
                     const uint64_t ri = (uint64_t)pool_item * 64u + l;
@@ -629,7 +656,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                         } else {
                             set_ray(tr.ray, o[0], o[1], o[2], d[0], d[1], d[2]);
                             trav_begin<COUNT>(s, tr, MISS, st.sp_init(tid), nbox);
-                            phase = PH_PRIMARY;
+                            phase = PH_PRIMARY | ray_pos_flag(tr.ray);
                         }
                     }
                 }
@@ -650,22 +677,43 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
             // others to finish their inner-node steps, but only until `leaf_thresh` lanes
             // are waiting (64 = classic while-while, 1 = if-if).  Per-lane order is
             // untouched, so results are too; only the wave's lane utilisation changes.
-            for (;;) {
-                // reference classes by one compare each: inner < REF_NONE (unsigned), leaf < 0 (signed)
-                const bool in = tr.cur < REF_NONE;
-                const unsigned long long m_in = __builtin_amdgcn_ballot_w64(in);
-                if (!m_in) break;
-                const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64((int32_t)tr.cur < 0);
-                if ((uint32_t)__popcll(m_leaf) >= p.leaf_thresh) break;
+            // Octant fast path: when every busy lane's ray lies in the same direction octant (always
+            // for the sun shadow rays, mostly for the camera rays of an 8x8 block) the visits use the
+            // octant's slab_sel: same bits, 12 fewer VALU per visit.  phase bits 2..5 = 8 | octant.
+            const uint32_t my_oct = (phase >> 2) & 15u;
+            const unsigned long long m_busy = __builtin_amdgcn_ballot_w64(tr.cur != REF_NONE);
+            const uint32_t oct0 = m_busy ? __builtin_amdgcn_readlane(my_oct, (int)__builtin_ctzll(m_busy)) : 0u;
+            const bool oct_wave = (oct0 & 8u) && __builtin_amdgcn_ballot_w64(tr.cur != REF_NONE && my_oct != oct0) == 0ull;
+            auto inner_loop = [&](auto pos_tag) __attribute__((always_inline)) {
+                constexpr int OCT = decltype(pos_tag)::value;
+                for (;;) {
+                    // reference classes by one compare each: inner < REF_NONE (unsigned), leaf < 0 (signed)
+                    const bool in = tr.cur < REF_NONE;
+                    const unsigned long long m_in = __builtin_amdgcn_ballot_w64(in);
+                    if (!m_in) break;
+                    const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64((int32_t)tr.cur < 0);
+                    if ((uint32_t)__popcll(m_leaf) >= p.leaf_thresh) break;
 #ifdef RTAMD_EXP_STAMPS
-                stamp_inner++; stamp_inner_lanes += __popcll(m_in);
-                {
-                    const uint32_t c0 = __builtin_amdgcn_readfirstlane(tr.cur);
-                    if (__ballot(in && tr.cur == c0) == m_in) stamp_uniform++;
-                }
+                    stamp_inner++; stamp_inner_lanes += __popcll(m_in);
+                    {
+                        const uint32_t c0 = __builtin_amdgcn_readfirstlane(tr.cur);
+                        if (__ballot(in && tr.cur == c0) == m_in) stamp_uniform++;
+                    }
 #endif
-                trav_inner_step<COUNT>(s, tr, st, tid, in, m_in, nbox);
-                item_work += 2;
+                    trav_inner_step<COUNT, OCT>(s, tr, st, tid, in, m_in, nbox);
+                    item_work += 2;
+                }
+            };
+            if (!oct_wave) inner_loop(std::integral_constant<int, -1>{});
+            else switch (oct0 & 7u) {
+                case 0: inner_loop(std::integral_constant<int, 0>{}); break;
+                case 1: inner_loop(std::integral_constant<int, 1>{}); break;
+                case 2: inner_loop(std::integral_constant<int, 2>{}); break;
+                case 3: inner_loop(std::integral_constant<int, 3>{}); break;
+                case 4: inner_loop(std::integral_constant<int, 4>{}); break;
+                case 5: inner_loop(std::integral_constant<int, 5>{}); break;
+                case 6: inner_loop(std::integral_constant<int, 6>{}); break;
+                default: inner_loop(std::integral_constant<int, 7>{}); break;
             }
             item_work += 3;
             if (item_work >= prio_next) {   // the longer a wave has held its item, the sooner the SIMD issues it
@@ -683,7 +731,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                 const unsigned long long m = __ballot(lf);
                 if (m) { stamp_leaf++; stamp_leaf_lanes += __popcll(m); }
 #endif
-                if (lf) trav_leaf<COUNT>(s, tr, st, tid, ntri, MODE == MODE_FUSED && p.shadow_anyhit && phase == PH_SHADOW);
+                if (lf) trav_leaf<COUNT>(s, tr, st, tid, ntri, MODE == MODE_FUSED && p.shadow_anyhit && (phase & PH_SHADOW));
 #ifdef RTAMD_EXP_STAMPS
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 tm_leaf += __builtin_amdgcn_s_memtime() - tm1;
@@ -698,14 +746,14 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                 *reinterpret_cast<float4 *>(p.hits + 4 * (size_t)out_index) = make_float4(tr.t, tr.u, tr.v, __uint_as_float(tr.idx));
                 if (COUNT && p.counts) { p.counts[2 * (size_t)out_index] = nbox; p.counts[2 * (size_t)out_index + 1] = ntri; }
                 phase = PH_IDLE;
-            } else if (phase == PH_PRIMARY) {
+            } else if (phase & PH_PRIMARY) {
                 prim_t = tr.t; prim_idx = tr.idx;
                 if (tr.t < T_HIT_LIMIT) {
                     Ray sray;
                     shade_primary(s, p, tr, col_shadow, col_lit, sray);
                     tr.ray = sray;
                     trav_begin<COUNT>(s, tr, T_PRIMARY0, st.sp_init(tid), nbox);
-                    phase = PH_SHADOW;
+                    phase = PH_SHADOW | ray_pos_flag(sray);
                 } else {
                     V3 c = skybox(tr.ray.dx, tr.ray.dy, tr.ray.dz);
                     if (p.rgba) *reinterpret_cast<float4 *>(p.rgba + 4 * (size_t)out_index) = make_float4(c.x, c.y, c.z, 1.0f);
