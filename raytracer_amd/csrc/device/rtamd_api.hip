@@ -71,7 +71,7 @@ struct rtamd_context {
     rtamd_scene_info info{};
     // measured defaults (tools/kbench.py): coherent camera/shadow rays run best without lane
     // re-fill (1), incoherent ray streams with re-fill below 32 busy lanes; leaves are
-    // released when 4 lanes wait
+    // released when 8 lanes wait
     uint32_t dyn_thresh_fused = 1, dyn_thresh_trace = 32;
     uint32_t leaf_thresh = 8;
     uint32_t prio_thresh = 0;
