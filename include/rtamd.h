@@ -181,6 +181,34 @@ int rtamd_generate_rays(rtamd_context *ctx, uint32_t width, uint32_t height, con
 int rtamd_generate_rays_device(rtamd_context *ctx, uint32_t width, uint32_t height, const float inv_proj_view[16],
                                float near_plane, float far_plane, float *dir_out);
 
+/* ---- secondary-ray generation: ray_trace/ray_dispatcher.frag:26-41 ---------- */
+
+/* The blue-noise texture (uniform location 2, res/textures/blue_noise.png via
+ * ResourceManager::get_texture, src/main.rs:53,171): an ordinary image texture, same
+ * upload and sampling rules as rtamd_upload_texture. */
+int rtamd_upload_noise_texture(rtamd_context *ctx, const uint8_t *rgb8, uint32_t width, uint32_t height);
+
+typedef struct rtamd_dispatch_desc {
+    uint32_t width, height;
+    const float *position;        /* G-buffer positionData (:18): 3 floats per pixel, row 0 = bottom */
+    const float *normal_mat;      /* G-buffer normalMatData (:19): 4 floats per pixel, xyz normal, w = material
+                                   * index bits, or 1e30 = "no surface" (clear value, src/main.rs:130) */
+    float light_pos[3];           /* uniform 3 */
+    float camera_pos[3];          /* uniform 4 */
+    float noise_offset_scale[4];  /* uniform 5: xy offset, zw scale (src/main.rs:161-166) */
+} rtamd_dispatch_desc;
+
+typedef struct rtamd_dispatch_out {
+    /* the four RGB32F colour attachments of the ray buffer (src/main.rs:68-72), 3 floats per pixel;
+     * any may be NULL.  Pixels without a surface get (0,0,0) = NO_RAY, the targets' clear value. */
+    float *org, *shadow_dir, *reflect_dir, *ambient_dir;
+} rtamd_dispatch_out;
+
+/* One pass of the dispatcher over the G-buffer.  The outputs feed rtamd_trace[_device]
+ * (org + one direction array per ray kind), exactly as src/main.rs:176-203 feeds ray_trace.frag. */
+int rtamd_dispatch_rays(rtamd_context *ctx, const rtamd_dispatch_desc *desc, const rtamd_dispatch_out *out);
+int rtamd_dispatch_rays_device(rtamd_context *ctx, const rtamd_dispatch_desc *desc, const rtamd_dispatch_out *out);
+
 /* ---- multi-GPU frame assembly helpers -------------------------------------- */
 
 /* Number of 32x32 tiles a rank owns, maximised over ranks (the per-rank block

@@ -72,6 +72,8 @@
     X(PFNGLUNIFORM1IPROC, glUniform1i) \
     X(PFNGLUNIFORM1FPROC, glUniform1f) \
     X(PFNGLUNIFORM1IVPROC, glUniform1iv) \
+    X(PFNGLUNIFORM3FPROC, glUniform3f) \
+    X(PFNGLUNIFORM4FPROC, glUniform4f) \
     X(PFNGLUNIFORMMATRIX4FVPROC, glUniformMatrix4fv) \
     X(PFNGLGENTEXTURESPROC, glGenTextures) \
     X(PFNGLDELETETEXTURESPROC, glDeleteTextures) \
@@ -476,5 +478,69 @@ int glslref_run_raycreate(int w, int h, const float *inv_proj_view, float near_,
     p_glDeleteFramebuffers(1, &fbo);
     p_glDeleteTextures(1, &target);
     if (e != GL_NO_ERROR) { snprintf(g_err, sizeof g_err, "GL error 0x%x during raycreate draw/readback", e); return -1; }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* secondary-ray generation: util/quad01.vert + ray_trace/ray_dispatcher.frag */
+/* G-buffer textures NEAREST (framebuffer_manager.rs:33), blue noise    */
+/* uploaded like every image texture (texture.rs:11-42, LINEAR), four   */
+/* RGB32F colour attachments cleared to 0 = NO_RAY (main.rs:68-72,156-158) */
+/* ------------------------------------------------------------------ */
+int glslref_run_dispatch(int w, int h, const float *position_rgb, const float *normal_mat_rgba,
+                         const uint8_t *noise_rgb, int nw, int nh,
+                         const float *light_pos, const float *camera_pos, const float *noise_offset_scale,
+                         float *out_org, float *out_shadow, float *out_reflect, float *out_ambient) {
+    if (!g_inited) { seterr("%s", "glslref_init not called"); return -1; }
+    GLuint prog = build_program("util/quad01.vert", "ray_trace/ray_dispatcher.frag");
+    if (!prog) return -1;
+    GLuint fbo, targets[4];
+    p_glGenFramebuffers(1, &fbo);
+    p_glBindFramebuffer(GL_FRAMEBUFFER, fbo);
+    p_glGenTextures(4, targets);
+    GLenum bufs[4];
+    for (int k = 0; k < 4; k++) {
+        p_glActiveTexture(GL_TEXTURE0 + 15);
+        p_glBindTexture(GL_TEXTURE_2D, targets[k]);
+        p_glTexImage2D(GL_TEXTURE_2D, 0, GL_RGB32F, w, h, 0, GL_RGB, GL_FLOAT, NULL);
+        p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
+        p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
+        p_glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0 + k, GL_TEXTURE_2D, targets[k], 0);
+        bufs[k] = GL_COLOR_ATTACHMENT0 + k;
+    }
+    p_glDrawBuffers(4, bufs);
+    if (p_glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) { seterr("%s", "dispatch framebuffer incomplete"); return -1; }
+    p_glViewport(0, 0, w, h);
+    p_glDisable(GL_DEPTH_TEST);
+    p_glDisable(GL_BLEND);
+    GLuint mats = make_ssbo(0, NULL, 0);   /* Material { bool reflect; }: read but never used (:36) */
+    GLuint t[3];
+    t[0] = make_float_tex(0, GL_RGB32F, GL_RGB, w, h, position_rgb);
+    t[1] = make_float_tex(1, GL_RGBA32F, GL_RGBA, w, h, normal_mat_rgba);
+    t[2] = make_albedo_tex(2, nw, nh, noise_rgb);
+    p_glUseProgram(prog);
+    p_glUniform1i(0, 0);
+    p_glUniform1i(1, 1);
+    p_glUniform1i(2, 2);
+    p_glUniform3f(3, light_pos[0], light_pos[1], light_pos[2]);
+    p_glUniform3f(4, camera_pos[0], camera_pos[1], camera_pos[2]);
+    p_glUniform4f(5, noise_offset_scale[0], noise_offset_scale[1], noise_offset_scale[2], noise_offset_scale[3]);
+    GLenum e = p_glGetError();
+    if (e != GL_NO_ERROR) { snprintf(g_err, sizeof g_err, "GL error 0x%x during dispatch setup", e); return -1; }
+    draw_timed(0, 1, 0, 0, 0, 0);
+    float *outs[4] = { out_org, out_shadow, out_reflect, out_ambient };
+    for (int k = 0; k < 4; k++) {
+        p_glReadBuffer(GL_COLOR_ATTACHMENT0 + k);
+        p_glReadPixels(0, 0, w, h, GL_RGB, GL_FLOAT, outs[k]);
+    }
+    e = p_glGetError();
+    p_glUseProgram(0);
+    p_glBindFramebuffer(GL_FRAMEBUFFER, 0);
+    p_glDeleteProgram(prog);
+    p_glDeleteFramebuffers(1, &fbo);
+    p_glDeleteTextures(4, targets);
+    p_glDeleteTextures(3, t);
+    p_glDeleteBuffers(1, &mats);
+    if (e != GL_NO_ERROR) { snprintf(g_err, sizeof g_err, "GL error 0x%x during dispatch draw/readback", e); return -1; }
     return 0;
 }

@@ -419,3 +419,49 @@ void oa_raycreate(uint32_t w, uint32_t h, const float *m /* column-major invProj
         }
     }
 }
+
+/* ray_trace/ray_dispatcher.frag:26-41 over a w x h G-buffer (row 0 = bottom): secondary-ray
+ * origins and the shadow / reflection / ambient-occlusion directions.  position: 3 floats
+ * per pixel (RGB32F, NEAREST, framebuffer_manager.rs:33), normal_mat: 4 floats per pixel
+ * (w == 1e30 marks "no surface": the fragment is discarded and the four targets keep their
+ * clear value 0 = NO_RAY, main.rs:157-158).  fragPos is the quad01.vert varying at the
+ * pixel centre; the blue-noise texture is an ordinary image texture (LINEAR, REPEAT).
+ * materials[] is read at :36 but never used.  No threads: one memory-bound pass. */
+void oa_dispatch(uint32_t w, uint32_t h, const float *position, const float *normal_mat,
+                 const uint8_t *noise_rgb, int nw, int nh,
+                 const float *light_pos, const float *camera_pos, const float *noise_offset_scale,
+                 float *org, float *shadow_dir, float *reflect_dir, float *ambient_dir) {
+    unsigned csr = _mm_getcsr();
+    apply_fp_mode();
+    oa_texture noise = { noise_rgb, nw, nh };
+    const v3 light = { light_pos[0], light_pos[1], light_pos[2] }, cam = { camera_pos[0], camera_pos[1], camera_pos[2] };
+    for (uint32_t py = 0; py < h; py++) {
+        const float fy = ((float)py + 0.5f) / (float)h;
+        for (uint32_t px = 0; px < w; px++) {
+            const size_t i = (size_t)py * w + px;
+            const float fx = ((float)px + 0.5f) / (float)w;
+            float *o = org + 3 * i, *sd = shadow_dir + 3 * i, *rd = reflect_dir + 3 * i, *ad = ambient_dir + 3 * i;
+            const float *nm = normal_mat + 4 * i;
+            if (nm[3] == 1e30f) {                                  /* :28 discard */
+                for (int k = 0; k < 3; k++) o[k] = sd[k] = rd[k] = ad[k] = 0.0f;
+                continue;
+            }
+            const v3 n = { nm[0], nm[1], nm[2] };
+            const v3 p = { position[3 * i], position[3 * i + 1], position[3 * i + 2] };
+            const v3 rnd = oa_sample_albedo(&noise, fx * noise_offset_scale[2] + noise_offset_scale[0],
+                                            fy * noise_offset_scale[3] + noise_offset_scale[1]);   /* :34 */
+            const v3 og = oa_add(p, oa_scale(n, 0.0001f));          /* :38 */
+            const v3 s = oa_normalize(oa_sub(light, p));            /* :39 */
+            const v3 inc = oa_sub(p, cam);
+            const float two_d = 2.0f * oa_dot(n, inc);              /* reflect(I,N) = I - 2*dot(N,I)*N */
+            const v3 r = oa_normalize(oa_sub(inc, oa_scale(n, two_d)));   /* :41 */
+            const v3 av = { (n.x + rnd.x * 2.0f) - 1.0f, (n.y + rnd.y * 2.0f) - 1.0f, (n.z + rnd.z * 2.0f) - 1.0f };
+            const v3 a = oa_normalize(av);                          /* :42 */
+            o[0] = og.x; o[1] = og.y; o[2] = og.z;
+            sd[0] = s.x; sd[1] = s.y; sd[2] = s.z;
+            rd[0] = r.x; rd[1] = r.y; rd[2] = r.z;
+            ad[0] = a.x; ad[1] = a.y; ad[2] = a.z;
+        }
+    }
+    _mm_setcsr(csr);
+}

@@ -54,6 +54,19 @@ class FrameOut(ctypes.Structure):
     ]
 
 
+class DispatchDesc(ctypes.Structure):
+    _fields_ = [
+        ("width", ctypes.c_uint32), ("height", ctypes.c_uint32),
+        ("position", ctypes.c_void_p), ("normal_mat", ctypes.c_void_p),
+        ("light_pos", ctypes.c_float * 3), ("camera_pos", ctypes.c_float * 3),
+        ("noise_offset_scale", ctypes.c_float * 4),
+    ]
+
+
+class DispatchOut(ctypes.Structure):
+    _fields_ = [("org", ctypes.c_void_p), ("shadow_dir", ctypes.c_void_p), ("reflect_dir", ctypes.c_void_p), ("ambient_dir", ctypes.c_void_p)]
+
+
 class SceneInfo(ctypes.Structure):
     _fields_ = [
         ("node_count", ctypes.c_uint32), ("triangle_count", ctypes.c_uint32), ("vertex_count", ctypes.c_uint32),
@@ -132,6 +145,11 @@ def device_lib():
             getattr(L, name).restype = ctypes.c_int
         for name in ("rtamd_generate_rays", "rtamd_generate_rays_device"):
             getattr(L, name).argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, c_float_p, ctypes.c_float, ctypes.c_float, vp]
+            getattr(L, name).restype = ctypes.c_int
+        L.rtamd_upload_noise_texture.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint32]
+        L.rtamd_upload_noise_texture.restype = ctypes.c_int
+        for name in ("rtamd_dispatch_rays", "rtamd_dispatch_rays_device"):
+            getattr(L, name).argtypes = [vp, ctypes.POINTER(DispatchDesc), ctypes.POINTER(DispatchOut)]
             getattr(L, name).restype = ctypes.c_int
         L.rtamd_tiles_per_rank.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
         L.rtamd_tiles_per_rank.restype = ctypes.c_uint32

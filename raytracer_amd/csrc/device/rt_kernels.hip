@@ -915,6 +915,83 @@ __global__ void __launch_bounds__(1024) k_reorder(const uint32_t *__restrict__ c
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_dispatch_rays — ray_trace/ray_dispatcher.frag:26-41: secondary-ray origins and the
+// shadow / reflection / ambient-occlusion directions from a G-buffer.
+// HBM-bound streaming kernel: 28 B in + 48 B out per pixel, noise texels from cache.
+// A block owns 256 consecutive pixels; the 12-B-per-pixel streams (position in, four
+// RGB32F targets out) go through LDS so that every global access is a full 16-B lane
+// access of a contiguous 3 KB run instead of three stride-12 dword accesses.
+// ---------------------------------------------------------------------------
+struct DispatchParams {
+    const float *position;     // 3 floats per pixel
+    const float *normal_mat;   // 4 floats per pixel; w == 1e30: no surface
+    const uint32_t *noise;     // RGBA8 texels
+    int32_t noise_w, noise_h;
+    float light[3], cam[3], nos[4];
+    uint32_t width, height, n;
+    float *out[4];             // org, shadowDir, reflectDir, ambientDir (any may be null)
+};
+
+__global__ void __launch_bounds__(256) k_dispatch_rays(const DispatchParams p) {
+    __shared__ float sh_in[768];
+    __shared__ float sh_out[4][768];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t base = blockIdx.x * 256u;
+    const uint32_t count = min(256u, p.n - base);
+    const bool full = count == 256u;
+    // stage the block's positions: 768 floats = 192 float4 (3*base*4 B is 16-B aligned: base % 256 == 0)
+    if (full) {
+        if (tid < 192u) reinterpret_cast<float4 *>(sh_in)[tid] = reinterpret_cast<const float4 *>(p.position + 3 * (size_t)base)[tid];
+    } else {
+        for (uint32_t k = tid; k < 3u * count; k += 256u) sh_in[k] = p.position[3 * (size_t)base + k];
+    }
+    __syncthreads();
+    const uint32_t i = base + tid;
+    float o[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};   // NO_RAY: the targets' clear value (main.rs:157)
+    if (tid < count) {
+        const float4 nm = reinterpret_cast<const float4 *>(p.normal_mat)[i];
+        if (!(nm.w == MISS)) {                                       // :28 discard
+            const uint32_t px = i % p.width, py = i / p.width;
+            const float fx = ((float)px + 0.5f) / (float)p.width, fy = ((float)py + 0.5f) / (float)p.height;   // quad01.vert:8 at the pixel centre
+            const float x = sh_in[3 * tid], y = sh_in[3 * tid + 1], z = sh_in[3 * tid + 2];
+            const V3 rnd = sample_albedo(p.noise, p.noise_w, p.noise_h, fx * p.nos[2] + p.nos[0], fy * p.nos[3] + p.nos[1]);   // :34
+            o[0][0] = x + nm.x * 0.0001f; o[0][1] = y + nm.y * 0.0001f; o[0][2] = z + nm.z * 0.0001f;                             // :38
+            {   // :39 normalize(lightPos - position)
+                const float dx = p.light[0] - x, dy = p.light[1] - y, dz = p.light[2] - z;
+                const float inv = 1.0f / sqrtf(dot_zyx(dx, dy, dz, dx, dy, dz));
+                o[1][0] = dx * inv; o[1][1] = dy * inv; o[1][2] = dz * inv;
+            }
+            {   // :41 normalize(reflect(position - cameraPos, normal)), reflect(I,N) = I - 2*dot(N,I)*N
+                const float ix = x - p.cam[0], iy = y - p.cam[1], iz = z - p.cam[2];
+                const float two_d = 2.0f * dot_zyx(nm.x, nm.y, nm.z, ix, iy, iz);
+                const float rx = ix - nm.x * two_d, ry = iy - nm.y * two_d, rz = iz - nm.z * two_d;
+                const float inv = 1.0f / sqrtf(dot_zyx(rx, ry, rz, rx, ry, rz));
+                o[2][0] = rx * inv; o[2][1] = ry * inv; o[2][2] = rz * inv;
+            }
+            {   // :42 normalize(normal + random * 2 - 1)
+                const float ax = (nm.x + rnd.x * 2.0f) - 1.0f, ay = (nm.y + rnd.y * 2.0f) - 1.0f, az = (nm.z + rnd.z * 2.0f) - 1.0f;
+                const float inv = 1.0f / sqrtf(dot_zyx(ax, ay, az, ax, ay, az));
+                o[3][0] = ax * inv; o[3][1] = ay * inv; o[3][2] = az * inv;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { sh_out[k][3 * tid] = o[k][0]; sh_out[k][3 * tid + 1] = o[k][1]; sh_out[k][3 * tid + 2] = o[k][2]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float *dst = p.out[k];
+        if (!dst) continue;
+        dst += 3 * (size_t)base;
+        if (full) {
+            if (tid < 192u) reinterpret_cast<float4 *>(dst)[tid] = reinterpret_cast<const float4 *>(sh_out[k])[tid];
+        } else {
+            for (uint32_t e = tid; e < 3u * count; e += 256u) dst[e] = sh_out[k][e];
+        }
+    }
+}
+
 // Root side of the gather: rank-major tile blocks -> scan-line frame.
 __global__ void k_assemble_tiles(const uint32_t *__restrict__ gathered, uint32_t width, uint32_t height, uint32_t world,
                                  uint32_t tiles_x, uint32_t tiles_per_rank, uint32_t elems, uint32_t *__restrict__ out) {

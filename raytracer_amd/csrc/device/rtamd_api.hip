@@ -60,6 +60,8 @@ struct rtamd_context {
     bool has_scene = false;
     DevBuf nodes, tris, big, tri_idx, normals, texcoords;
     DevBuf tex[2];
+    DevBuf noise;
+    int32_t noise_w = 0, noise_h = 0;
     int32_t tex_w[2] = {1, 1}, tex_h[2] = {1, 1};
     DevBuf white;
     bool adaptive_order = false;
@@ -331,7 +333,7 @@ void rtamd_context_destroy(rtamd_context *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();   // launches may be in flight on several (caller-owned) streams
     ctx->nodes.release(); ctx->tris.release(); ctx->big.release(); ctx->tri_idx.release();
-    ctx->normals.release(); ctx->texcoords.release(); ctx->tex[0].release(); ctx->tex[1].release();
+    ctx->normals.release(); ctx->texcoords.release(); ctx->tex[0].release(); ctx->tex[1].release(); ctx->noise.release();
     ctx->white.release(); ctx->ipv.release();
     for (auto &sl : ctx->slots) {
         sl.queues.release(); sl.spill.release(); sl.item_cost.release(); sl.item_order.release();
@@ -529,35 +531,103 @@ int rtamd_upload_scene(rtamd_context *ctx, const rtamd_scene_desc *sc) {
     return RTAMD_OK;
 }
 
-int rtamd_upload_texture(rtamd_context *ctx, uint32_t slot, const uint8_t *rgb8, uint32_t width, uint32_t height) {
-    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
-    if (slot > 1) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "texture slot %u: the shader has modelTextures[2]", slot);
+namespace {
+// GL_RGB / UNSIGNED_BYTE rows (taken as tightly packed, first row first) -> RGBA8 texels in HBM.
+int upload_rgb8(rtamd_context *ctx, DevBuf &dst, const uint8_t *rgb8, uint32_t width, uint32_t height) {
     if (!rgb8 || width == 0 || height == 0 || width > 32768 || height > 32768) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "bad texture %ux%u", width, height);
     int rc = ensure_ctx_device(ctx);
     if (rc) return rc;
     try {
-        // GL_RGB / UNSIGNED_BYTE rows with the default GL_UNPACK_ALIGNMENT of 4
-        // (texture.rs:14-24 never changes it) into RGBA8.
-        const size_t row_stride = ((size_t)width * 3 + 3) & ~(size_t)3;
-        const bool tight = row_stride == (size_t)width * 3;
+        // The reference uploads with the default GL_UNPACK_ALIGNMENT of 4 (texture.rs:14-24 never
+        // changes it); a caller that hands over tightly packed rows whose length is not a multiple
+        // of 4 would be mis-read by GL.  We take the rows as tightly packed (what the caller means).
         std::vector<uint32_t> rgba((size_t)width * height);
         for (uint32_t y = 0; y < height; y++) {
-            // A caller that hands over tightly packed rows whose length is not a
-            // multiple of 4 would be mis-read by GL; we take the rows as tightly
-            // packed (what the caller means) and document the difference.
             const uint8_t *row = rgb8 + (size_t)y * (size_t)width * 3;
-            (void)tight;
             for (uint32_t x = 0; x < width; x++)
                 rgba[(size_t)y * width + x] = (uint32_t)row[3 * x] | ((uint32_t)row[3 * x + 1] << 8) | ((uint32_t)row[3 * x + 2] << 16) | 0xFF000000u;
         }
-        if ((rc = dev_upload(ctx, ctx->tex[slot], rgba.data(), rgba.size() * 4))) return rc;
+        // a frame in flight may still sample the old texels
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        if ((rc = dev_upload(ctx, dst, rgba.data(), rgba.size() * 4))) return rc;
     } catch (const std::bad_alloc &) {
         return fail(ctx, RTAMD_ERR_OUT_OF_MEMORY, "out of host memory");
     }
+    return RTAMD_OK;
+}
+}  // namespace
+
+int rtamd_upload_texture(rtamd_context *ctx, uint32_t slot, const uint8_t *rgb8, uint32_t width, uint32_t height) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (slot > 1) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "texture slot %u: the shader has modelTextures[2]", slot);
+    int rc = upload_rgb8(ctx, ctx->tex[slot], rgb8, width, height);
+    if (rc) return rc;
     ctx->tex_w[slot] = (int32_t)width; ctx->tex_h[slot] = (int32_t)height;
     ctx->sdev.tex[slot] = (const uint32_t *)ctx->tex[slot].p;
     ctx->sdev.tex_w[slot] = (int32_t)width; ctx->sdev.tex_h[slot] = (int32_t)height;
     return RTAMD_OK;
+}
+
+int rtamd_upload_noise_texture(rtamd_context *ctx, const uint8_t *rgb8, uint32_t width, uint32_t height) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    int rc = upload_rgb8(ctx, ctx->noise, rgb8, width, height);
+    if (rc) return rc;
+    ctx->noise_w = (int32_t)width; ctx->noise_h = (int32_t)height;
+    return RTAMD_OK;
+}
+
+int rtamd_dispatch_rays_device(rtamd_context *ctx, const rtamd_dispatch_desc *d, const rtamd_dispatch_out *o) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (!d || !o) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "dispatch descriptor / output is NULL");
+    if (!ctx->noise.p) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "no noise texture uploaded (rtamd_upload_noise_texture)");
+    if (d->width == 0 || d->height == 0 || (uint64_t)d->width * d->height > 0x7FFFFFFFull) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "bad frame size %ux%u", d->width, d->height);
+    if (!d->position || !d->normal_mat) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "position / normal_mat is NULL");
+    if (((uintptr_t)d->position | (uintptr_t)d->normal_mat | (uintptr_t)o->org | (uintptr_t)o->shadow_dir | (uintptr_t)o->reflect_dir | (uintptr_t)o->ambient_dir) & 15u)
+        return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "device buffers must be 16-byte aligned");
+    int rc = ensure_ctx_device(ctx);
+    if (rc) return rc;
+    DispatchParams p{};
+    p.position = d->position; p.normal_mat = d->normal_mat;
+    p.noise = (const uint32_t *)ctx->noise.p; p.noise_w = ctx->noise_w; p.noise_h = ctx->noise_h;
+    std::memcpy(p.light, d->light_pos, sizeof p.light);
+    std::memcpy(p.cam, d->camera_pos, sizeof p.cam);
+    std::memcpy(p.nos, d->noise_offset_scale, sizeof p.nos);
+    p.width = d->width; p.height = d->height; p.n = d->width * d->height;
+    p.out[0] = o->org; p.out[1] = o->shadow_dir; p.out[2] = o->reflect_dir; p.out[3] = o->ambient_dir;
+    hipLaunchKernelGGL(k_dispatch_rays, dim3((p.n + 255u) / 256u), dim3(256), 0, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    return RTAMD_OK;
+}
+
+int rtamd_dispatch_rays(rtamd_context *ctx, const rtamd_dispatch_desc *d, const rtamd_dispatch_out *o) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (!d || !o) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "dispatch descriptor / output is NULL");
+    if (d->width == 0 || d->height == 0 || !d->position || !d->normal_mat) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "bad dispatch arguments");
+    int rc = ensure_ctx_device(ctx);
+    if (rc) return rc;
+    const size_t n = (size_t)d->width * d->height;
+    DevBuf d_pos, d_nm, d_out[4];
+    float *host_out[4] = {o->org, o->shadow_dir, o->reflect_dir, o->ambient_dir};
+    rtamd_dispatch_desc dd = *d;
+    rtamd_dispatch_out od{};
+    float **dev_out[4] = {&od.org, &od.shadow_dir, &od.reflect_dir, &od.ambient_dir};
+    rc = RTAMD_OK;
+    do {
+        if ((rc = dev_upload(ctx, d_pos, d->position, n * 12))) break;
+        if ((rc = dev_upload(ctx, d_nm, d->normal_mat, n * 16))) break;
+        dd.position = (const float *)d_pos.p; dd.normal_mat = (const float *)d_nm.p;
+        for (int k = 0; k < 4 && !rc; k++)
+            if (host_out[k]) { if (!(rc = dev_alloc(ctx, d_out[k], n * 12))) *dev_out[k] = (float *)d_out[k].p; }
+        if (rc) break;
+        if ((rc = rtamd_dispatch_rays_device(ctx, &dd, &od))) break;
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { rc = fail(ctx, RTAMD_ERR_DEVICE, "dispatch kernel failed: %s", hipGetErrorString(e)); break; }
+        for (int k = 0; k < 4; k++)
+            if (host_out[k] && (e = hipMemcpy(host_out[k], d_out[k].p, n * 12, hipMemcpyDeviceToHost)) != hipSuccess) { rc = fail(ctx, RTAMD_ERR_DEVICE, "copy-back failed: %s", hipGetErrorString(e)); break; }
+    } while (0);
+    d_pos.release(); d_nm.release();
+    for (auto &b : d_out) b.release();
+    return rc;
 }
 
 int rtamd_render_device(rtamd_context *ctx, const rtamd_frame_desc *desc, const rtamd_frame_out *out) {

@@ -181,6 +181,41 @@ class HipRayTracer:
         self._check(self._lib.rtamd_generate_rays_device(self._h, width, height, inv.ctypes.data_as(_ffi.c_float_p), NEAR, FAR,
                                                          ctypes.c_void_p(dir_ptr)))
 
+    # ---- secondary rays (ray_dispatcher.frag) -------------------------------
+    def upload_noise_texture(self, rgb8):
+        t = np.ascontiguousarray(rgb8, dtype=np.uint8)
+        if t.ndim != 3 or t.shape[2] != 3:
+            raise ValueError("noise texture must be (h, w, 3) uint8")
+        self._check(self._lib.rtamd_upload_noise_texture(self._h, _ptr(t), t.shape[1], t.shape[0]))
+
+    def _dispatch_desc(self, width, height, position_ptr, normal_mat_ptr, light_pos, camera_pos, noise_offset_scale):
+        d = _ffi.DispatchDesc()
+        d.width, d.height = width, height
+        d.position, d.normal_mat = position_ptr, normal_mat_ptr
+        d.light_pos[:] = [float(x) for x in light_pos]
+        d.camera_pos[:] = [float(x) for x in camera_pos]
+        d.noise_offset_scale[:] = [float(x) for x in noise_offset_scale]
+        return d
+
+    def dispatch_rays(self, position, normal_mat, light_pos, camera_pos, noise_offset_scale):
+        """(h, w, 3) positions + (h, w, 4) normal/material G-buffer -> dict of four (h, w, 3) arrays."""
+        p = np.ascontiguousarray(position, dtype=np.float32)
+        nm = np.ascontiguousarray(normal_mat, dtype=np.float32)
+        h, w = nm.shape[:2]
+        if p.shape != (h, w, 3) or nm.shape != (h, w, 4):
+            raise ValueError("position must be (h, w, 3) and normal_mat (h, w, 4)")
+        outs = {k: np.zeros((h, w, 3), np.float32) for k in ("org", "shadow_dir", "reflect_dir", "ambient_dir")}
+        d = self._dispatch_desc(w, h, _ptr(p).value, _ptr(nm).value, light_pos, camera_pos, noise_offset_scale)
+        o = _ffi.DispatchOut(*(_ptr(outs[k]).value for k in ("org", "shadow_dir", "reflect_dir", "ambient_dir")))
+        self._check(self._lib.rtamd_dispatch_rays(self._h, ctypes.byref(d), ctypes.byref(o)))
+        return outs
+
+    def dispatch_rays_device(self, width, height, position_ptr, normal_mat_ptr, light_pos, camera_pos, noise_offset_scale,
+                             org_ptr=0, shadow_dir_ptr=0, reflect_dir_ptr=0, ambient_dir_ptr=0):
+        d = self._dispatch_desc(width, height, position_ptr, normal_mat_ptr, light_pos, camera_pos, noise_offset_scale)
+        o = _ffi.DispatchOut(org_ptr or None, shadow_dir_ptr or None, reflect_dir_ptr or None, ambient_dir_ptr or None)
+        self._check(self._lib.rtamd_dispatch_rays_device(self._h, ctypes.byref(d), ctypes.byref(o)))
+
     def assemble_tiles_device(self, gathered_ptr, width, height, tile_world, elems_per_pixel, frame_ptr):
         self._check(self._lib.rtamd_assemble_tiles_device(self._h, ctypes.c_void_p(gathered_ptr), width, height, tile_world,
                                                           elems_per_pixel, ctypes.c_void_p(frame_ptr)))

@@ -10,6 +10,8 @@ GOLDEN_SCENES = ("cube", "f16", "teapot", "bunny")
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN_DIR, f"golden_{name}.npz"), allow_pickle=False)
     g = {k: z[k] for k in z.files}
+    if "nodes" not in g:
+        return g
     g["scene"] = {"nodes": g["nodes"], "triangles": g["triangles"], "positions": g["positions"],
                   "tex_coords": g.get("tex_coords"), "normals": g.get("normals")}
     return g
@@ -43,3 +45,23 @@ def rgb_err_255(a, b):
     a = np.clip(np.asarray(a, np.float64)[..., :3], 0, 1)
     b = np.clip(np.asarray(b, np.float64)[..., :3], 0, 1)
     return np.abs(a - b).max(-1) * 255.0
+
+
+DISPATCH_KEYS = ("org", "shadow_dir", "reflect_dir", "ambient_dir")
+# ambientDir goes through a LINEAR texture fetch whose weights depend on the rasteriser's
+# interpolated fragPos (not bit-reproducible); everything else must match llvmpipe bit for bit
+DISPATCH_AMBIENT_TOL = 1e-5
+
+
+def check_dispatch(got, g):
+    """got: dict of (h, w, 3) arrays; g: golden_dispatch fixture (llvmpipe outputs b_*)."""
+    surface = g["normal_mat"][..., 3] != np.float32(1e30)
+    assert 3000 < surface.sum() < surface.size
+    for k in DISPATCH_KEYS:
+        assert np.all(got[k][~surface] == 0), k                      # discarded fragments keep NO_RAY
+        assert np.all(g["b_" + k][~surface] == 0), k
+    for k in ("org", "shadow_dir", "reflect_dir"):
+        assert np.array_equal(bits(got[k]), bits(g["b_" + k])), k
+    assert np.abs(got["ambient_dir"] - g["b_ambient_dir"]).max() <= DISPATCH_AMBIENT_TOL
+    n = np.linalg.norm(got["ambient_dir"][surface].astype(np.float64), axis=-1)
+    assert np.abs(n - 1).max() < 1e-6

@@ -11,6 +11,9 @@ inputs + outputs as compressed .npz files:
   outputs  b_trace  (h, w, 4)  ray_trace/ray_trace.frag   -> (t, u, v, bits(idx))
            b_fused  (h, w, 4)  ray_trace_and_shade.frag   -> fragCol
            b_trace_rand (n, 1, 4) same shader on incoherent rays (secondary-ray stand-in)
+  golden_dispatch.npz: ray_trace/ray_dispatcher.frag on a G-buffer (positions, flat normals,
+           material bits / 1e30 "no surface") derived from the bunny frame, a seeded 64x64
+           unit-vector noise texture -> b_org, b_shadow_dir, b_reflect_dir, b_ambient_dir
 
 The fixtures are data only.  Usage:  python tests/golden/make_golden.py
 """
@@ -101,6 +104,35 @@ def main():
         hits = int((b_trace[..., 0] < 1e30).sum())
         print(f"{name}: {len(sc['triangles'])} tris, {len(sc['nodes'])} nodes, {hits}/{W * H} hit pixels, "
               f"{int((b_rand[..., 0] < 1e30).sum())}/4096 random hits -> {os.path.getsize(path) / 1e6:.2f} MB")
+
+    # secondary-ray dispatcher on a G-buffer derived from the bunny frame just written
+    g = dict(np.load(os.path.join(HERE, "golden_bunny.npz")))
+    tr = g["b_trace"]
+    t = tr[..., 0]
+    hit = t < 1e30
+    idx = np.ascontiguousarray(tr[..., 3]).view(np.uint32)
+    gpos = (g["org"] + g["dir"] * t[..., None]).astype(np.float32)
+    gpos[~hit] = 0
+    tri, P = g["triangles"], g["positions"]
+    p0, p1, p2 = P[tri["p0"][idx]], P[tri["p1"][idx]], P[tri["p2"][idx]]
+    nrm = np.cross(p1 - p0, p2 - p0)
+    nrm = (nrm / np.maximum(1e-30, np.linalg.norm(nrm, axis=-1, keepdims=True))).astype(np.float32)
+    nm = np.zeros((H, W, 4), np.float32)
+    nm[..., :3] = nrm
+    mat_bits = (idx & 1).astype(np.uint32).view(np.float32)          # floatBitsToInt(normalMat.w), :31
+    nm[..., 3] = np.where(hit, mat_bits, np.float32(1e30))           # 1e30 = "no material", main.rs:130
+    rng = np.random.default_rng(7)
+    v = rng.normal(size=(64, 64, 3))
+    v /= np.linalg.norm(v, axis=-1, keepdims=True)
+    noise = np.clip(np.round((v * 0.5 + 0.5) * 255), 0, 255).astype(np.uint8)   # "is unit length vector", :20
+    light = np.array([3.0, 20.0, -4.0], np.float32)
+    cam_pos = g["org"][0, 0].astype(np.float32)
+    nos = np.array([5 / 64, 9 / 64, W / 64, H / 64], np.float32)    # offset on the texel grid, scale = frame / noise (main.rs:161-166)
+    d = B.dispatch(gpos, nm, noise, light, cam_pos, nos)
+    np.savez_compressed(os.path.join(HERE, "golden_dispatch.npz"), position=gpos, normal_mat=nm, noise=noise, light_pos=light,
+                        camera_pos=cam_pos, noise_offset_scale=nos, b_org=d["org"], b_shadow_dir=d["shadow_dir"],
+                        b_reflect_dir=d["reflect_dir"], b_ambient_dir=d["ambient_dir"], renderer=np.array(B.renderer))
+    print("dispatch:", int(hit.sum()), "surface pixels of", W * H, "->", os.path.getsize(os.path.join(HERE, "golden_dispatch.npz")) / 1e6, "MB")
 
     # special values: axis-parallel rays (1/0 = inf, 0*inf = NaN in the slab test),
     # origins on box planes, denormal coordinates (llvmpipe runs FTZ/DAZ)

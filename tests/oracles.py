@@ -53,6 +53,21 @@ def build_oracle_a():
     subprocess.run(["make", "-s", "-C", os.path.join(REPO, "oracle"), "all"], check=True)
 
 
+def _dispatch_call(fn, position, normal_mat, noise_rgb, light_pos, camera_pos, noise_offset_scale, size_first):
+    p = np.ascontiguousarray(position, dtype=np.float32)
+    nm = np.ascontiguousarray(normal_mat, dtype=np.float32)
+    h, w = nm.shape[:2]
+    assert p.shape == (h, w, 3) and nm.shape == (h, w, 4)
+    noise = np.ascontiguousarray(noise_rgb, dtype=np.uint8)
+    lp = np.ascontiguousarray(light_pos, dtype=np.float32)
+    cp = np.ascontiguousarray(camera_pos, dtype=np.float32)
+    nos = np.ascontiguousarray(noise_offset_scale, dtype=np.float32)
+    outs = [np.zeros((h, w, 3), np.float32) for _ in range(4)]
+    fn(w, h, p.ctypes.data, nm.ctypes.data, noise.ctypes.data, noise.shape[1], noise.shape[0], lp.ctypes.data, cp.ctypes.data,
+       nos.ctypes.data, *(o.ctypes.data for o in outs))
+    return dict(zip(("org", "shadow_dir", "reflect_dir", "ambient_dir"), outs))
+
+
 class OracleA:
     def __init__(self):
         if not os.path.exists(ORACLE_A_PATH):
@@ -68,7 +83,13 @@ class OracleA:
         L.oa_raycreate.argtypes = [ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_float, ctypes.c_float, vp]
         L.oa_raycreate.restype = None
         L.oa_set_flush_denormals.argtypes = [ctypes.c_int]
+        L.oa_dispatch.argtypes = [ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp]
+        L.oa_dispatch.restype = None
         self.L = L
+
+    def dispatch(self, position, normal_mat, noise_rgb, light_pos, camera_pos, noise_offset_scale):
+        """ray_dispatcher.frag over an (h, w) G-buffer (row 0 = bottom) -> dict(org, shadow_dir, reflect_dir, ambient_dir)."""
+        return _dispatch_call(self.L.oa_dispatch, position, normal_mat, noise_rgb, light_pos, camera_pos, noise_offset_scale, size_first=True)
 
     def set_flush_denormals(self, on):
         self.L.oa_set_flush_denormals(int(on))
@@ -129,6 +150,7 @@ class OracleB:
         L.glslref_run_trace.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(_Scene), vp, vp, vp,
                                         ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         L.glslref_run_raycreate.argtypes = [ctypes.c_int, ctypes.c_int, vp, ctypes.c_float, ctypes.c_float, vp]
+        L.glslref_run_dispatch.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp]
         if L.glslref_init(shader_root.encode()) != 0:
             raise RuntimeError("glslref_init: " + L.glslref_last_error().decode())
         self.L = L
@@ -164,6 +186,11 @@ class OracleB:
         self._check(self.L.glslref_run_trace(w, h, ctypes.byref(sc), d.ctypes.data, o.ctypes.data, out.ctypes.data,
                                              warm, reps, ctypes.byref(med)))
         return out, med.value
+
+    def dispatch(self, position, normal_mat, noise_rgb, light_pos, camera_pos, noise_offset_scale):
+        def call(*a):
+            self._check(self.L.glslref_run_dispatch(*a))
+        return _dispatch_call(call, position, normal_mat, noise_rgb, light_pos, camera_pos, noise_offset_scale, size_first=True)
 
     def raycreate(self, width, height, inv_proj_view, near, far):
         m = np.ascontiguousarray(inv_proj_view, dtype=np.float32).reshape(16)

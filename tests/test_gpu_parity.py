@@ -4,7 +4,7 @@ same seeded inputs."""
 import numpy as np
 import pytest
 
-from common import GOLDEN_SCENES, bits, load_golden, mixed_material_mask, rgb_err_255
+from common import DISPATCH_KEYS, GOLDEN_SCENES, bits, check_dispatch, load_golden, mixed_material_mask, rgb_err_255
 
 pytestmark = pytest.mark.gpu
 
@@ -75,3 +75,56 @@ def test_fused_render_matches_reference_shader(tracer, oracle_a, name, variant, 
     assert err_b[~mixed].max() <= 1.0
     assert rgb_err_255(r["rgba"], a["rgba"]).max() <= 0.05
     assert np.all(r["rgba"][:, 3] == 1.0)
+
+
+def test_ray_dispatcher_matches_reference_shader(tracer, oracle_a):
+    """k_dispatch_rays vs ray_dispatcher.frag on llvmpipe (fixture) and vs oracle A, through the host
+    entry point; then ragged sizes (partial last block, sizes below one block) vs oracle A bit for bit."""
+    g = load_golden("dispatch")
+    tracer.upload_noise_texture(g["noise"])
+    args = (g["light_pos"], g["camera_pos"], g["noise_offset_scale"])
+    r = tracer.dispatch_rays(g["position"], g["normal_mat"], *args)
+    check_dispatch(r, g)
+    a = oracle_a.dispatch(g["position"], g["normal_mat"], g["noise"], *args)
+    for k in DISPATCH_KEYS:
+        assert np.array_equal(bits(r[k]), bits(a[k])), k          # same float bilinear on both sides
+    for h, w in ((7, 150), (1, 1), (3, 85), (2, 256)):
+        p, nm = g["position"][:h, :w], g["normal_mat"][:h, :w]
+        r = tracer.dispatch_rays(p, nm, *args)
+        a = oracle_a.dispatch(p, nm, g["noise"], *args)
+        for k in DISPATCH_KEYS:
+            assert np.array_equal(bits(r[k]), bits(a[k])), (h, w, k)
+
+
+def test_ray_dispatcher_device_entry_and_trace_pipeline(tracer, oracle_a):
+    """The v0 pipeline of src/main.rs:156-203 on device buffers: dispatcher -> three ray_trace passes
+    (shadow, reflection, ambient rays); every hit record equals oracle A's for the same rays, and
+    pixels without a surface (NO_RAY) keep the cleared record."""
+    import torch
+    g = load_golden("dispatch")
+    b = load_golden("bunny")
+    tracer.upload_scene(b["scene"])
+    tracer.upload_noise_texture(g["noise"])
+    h, w = g["normal_mat"].shape[:2]
+    n = h * w
+    dev = torch.device("cuda", 0)
+    d_pos = torch.from_numpy(g["position"].reshape(n, 3)).to(dev)
+    d_nm = torch.from_numpy(g["normal_mat"].reshape(n, 4)).to(dev)
+    outs = {k: torch.full((n, 3), 7.0, dtype=torch.float32, device=dev) for k in DISPATCH_KEYS}
+    tracer.dispatch_rays_device(w, h, d_pos.data_ptr(), d_nm.data_ptr(), g["light_pos"], g["camera_pos"], g["noise_offset_scale"],
+                                **{k + "_ptr": v.data_ptr() for k, v in outs.items()})
+    hits = {}
+    for k in DISPATCH_KEYS[1:]:
+        hits[k] = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+        tracer.trace_device(n, outs["org"].data_ptr(), outs[k].data_ptr(), hits[k].data_ptr())
+    tracer.synchronize()
+    a = oracle_a.dispatch(g["position"], g["normal_mat"], g["noise"], g["light_pos"], g["camera_pos"], g["noise_offset_scale"])
+    surface = (g["normal_mat"][..., 3] != np.float32(1e30)).reshape(-1)
+    for k in DISPATCH_KEYS:
+        assert np.array_equal(bits(outs[k].cpu().numpy()), bits(a[k].reshape(n, 3))), k
+    for k in DISPATCH_KEYS[1:]:
+        want = oracle_a.trace(b["scene"], a["org"], a[k])["hits"]
+        got = hits[k].cpu().numpy()
+        assert np.array_equal(bits(got), bits(want)), k
+        assert np.all(got[~surface, 0] == np.float32(1e30)) and np.all(got[~surface, 1:] == 0)
+    assert (hits["shadow_dir"].cpu().numpy()[surface, 0] < 1e30).sum() > 100   # some surface points are shadowed
