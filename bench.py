@@ -54,7 +54,7 @@ def build_workload(name):
         tex = (None, None)
     else:
         raise SystemExit(f"unknown workload {name}")
-    model.build_bvh()
+    model.build_bvh(min(16, os.cpu_count() or 1))   # BVHBuilder::build_parallel: the serial build's tree, bit for bit
     d = np.asarray(cam["direction"], np.float32)
     d /= np.linalg.norm(d)
     camera = host.Camera(w / h, fov=math.radians(cam["fov_deg"]), position=cam["position"], direction=d)

@@ -37,6 +37,9 @@ void rtamd_model_free(rtamd_model *m);
 /* Model::build_bvh (model.rs:36) = BVHBuilder::new(model).build()
  * (src/raytracing/bvh.rs:61-79): binned SAH, reorders the model's triangles. */
 int rtamd_model_build_bvh(rtamd_model *m);
+/* The same BVH (nodes, numbering, triangle order: bit for bit) built on `threads` host threads;
+ * SURVEY section 8 row f3, no counterpart in the reference (bvh.rs:150-242 is single-threaded). */
+int rtamd_model_build_bvh_parallel(rtamd_model *m, uint32_t threads);
 
 typedef struct rtamd_model_info {
     uint32_t triangle_count, vertex_count, node_count, material_count;

@@ -95,6 +95,8 @@ def host_lib():
         L.rtamd_model_free.restype = None
         L.rtamd_model_build_bvh.argtypes = [ctypes.c_void_p]
         L.rtamd_model_build_bvh.restype = ctypes.c_int
+        L.rtamd_model_build_bvh_parallel.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+        L.rtamd_model_build_bvh_parallel.restype = ctypes.c_int
         L.rtamd_model_get_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ModelInfo)]
         L.rtamd_model_get_info.restype = None
         for name in ("rtamd_model_triangles", "rtamd_model_positions", "rtamd_model_tex_coords",

@@ -21,6 +21,13 @@ class BVHBuilder {
 public:
     explicit BVHBuilder(Model &model);  // bvh.rs:61-67
     BVH build();                        // bvh.rs:69-79 (consumes the builder)
+    // Same tree, same node numbering, same triangle permutation as build(), bit for bit, on
+    // `threads` host threads (no counterpart in the reference, whose build is
+    // single-threaded).  Split decisions depend only on a node's triangle range, so the top of
+    // the tree is split with chunk-parallel binning (min / max / count reductions merged in chunk
+    // order are exact), the subtrees below are built by independent tasks with local numbering,
+    // and one depth-first pass that replays build()'s allocation order relocates them.
+    BVH build_parallel(unsigned threads);
 
     static constexpr size_t BINS = 50;  // bvh.rs:151
 
@@ -39,6 +46,12 @@ private:
     Split find_best_split_binned(size_t first_tri, size_t tri_count) const;  // bvh.rs:150-204
     // bvh.rs:208-242; returns true and appends two children when the node was split
     bool split_leaf_node_sah(size_t node_idx);
+
+    // pieces of build() usable on any node vector / from any thread (disjoint triangle ranges)
+    Split find_best_split_chunked(size_t first_tri, size_t tri_count, unsigned threads) const;
+    AABB aabb_from_triangles_chunked(size_t first, size_t count, unsigned threads) const;
+    void build_subtree(std::vector<BVHNode> &out, size_t first, size_t count, const AABB &bounds);
+    BVH finish(std::vector<BVHNode> nodes);
 
     Model &model_;
     std::vector<BVHTriangle> triangles_;

@@ -77,6 +77,16 @@ int rtamd_model_build_bvh(rtamd_model *m) {
     }
 }
 
+int rtamd_model_build_bvh_parallel(rtamd_model *m, uint32_t threads) {
+    if (!m) return -1;
+    try {
+        m->model.build_bvh_parallel(threads);
+        return 0;
+    } catch (const std::exception &) {
+        return -100;
+    }
+}
+
 void rtamd_model_get_info(const rtamd_model *m, rtamd_model_info *info) {
     if (!m || !info) return;
     const Model &md = m->model;

@@ -8,6 +8,7 @@ namespace rtamd {
 namespace host {
 
 void Model::build_bvh() { bvh_ = std::make_unique<BVH>(BVHBuilder(*this).build()); }
+void Model::build_bvh_parallel(unsigned threads) { bvh_ = std::make_unique<BVH>(BVHBuilder(*this).build_parallel(threads)); }
 
 Model Model::from_arrays(std::vector<Triangle> triangles, std::vector<Vec3> positions,
                          const std::vector<Vec2> *tex_coords, const std::vector<Vec3> *normals) {

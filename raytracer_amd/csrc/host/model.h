@@ -38,6 +38,7 @@ public:
     void set_triangles(std::vector<Triangle> t) { triangles_ = std::move(t); }
     void set_indices(std::vector<uint32_t> i) { indices_ = std::move(i); }
     void build_bvh();  // model.rs:36
+    void build_bvh_parallel(unsigned threads);  // same BVH bit for bit (BVHBuilder::build_parallel)
     const std::vector<std::string> &get_material_libs() const { return material_libs_; }
     const std::vector<std::string> &get_materials() const { return materials_; }
     const BVH *get_bvh() const { return bvh_ ? bvh_.get() : nullptr; }

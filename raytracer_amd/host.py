@@ -7,6 +7,7 @@ Model.build_bvh -> BVHBuilder (src/raytracing/bvh.rs:60-243), Camera
 computation happens in raytracer_amd/csrc/host/*.cpp.
 """
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -69,8 +70,9 @@ class Model:
         self._lib.rtamd_model_get_info(self._h, ctypes.byref(i))
         return i
 
-    def build_bvh(self):
-        rc = self._lib.rtamd_model_build_bvh(self._h)
+    def build_bvh(self, threads=1):
+        """threads > 1: BVHBuilder::build_parallel — the same tree bit for bit, built on several host threads."""
+        rc = self._lib.rtamd_model_build_bvh(self._h) if threads <= 1 else self._lib.rtamd_model_build_bvh_parallel(self._h, int(threads))
         if rc != 0:
             raise RuntimeError(f"build_bvh failed ({rc})")
 
@@ -109,6 +111,36 @@ class Model:
             raise RuntimeError("build_bvh() first")
         return {"nodes": nodes, "triangles": self.triangles(), "positions": self.positions(),
                 "tex_coords": self.tex_coords(), "normals": self.normals()}
+
+
+# ---- on-disk cache of a built scene ("BVH built once ... and cached") -------------
+# One .npz with the five upload slices exactly as rtamd_upload_scene takes them (36-B nodes, 16-B
+# triangles in leaf order, packed attribute streams) plus a format tag; loading needs no rebuild and
+# no model object.  np.load with allow_pickle=False: the file carries plain arrays only.
+SCENE_CACHE_FORMAT = "rtamd-scene-1"
+
+
+def save_scene(path, scene):
+    arrays = {"format": np.array(SCENE_CACHE_FORMAT), "nodes": np.ascontiguousarray(scene["nodes"]),
+              "triangles": np.ascontiguousarray(scene["triangles"]), "positions": np.ascontiguousarray(scene["positions"])}
+    for k in ("tex_coords", "normals"):
+        if scene.get(k) is not None:
+            arrays[k] = np.ascontiguousarray(scene[k])
+    tmp = f"{path}.tmp.{os.getpid()}.npz"
+    np.savez(tmp, **arrays)
+    os.replace(tmp, path)
+
+
+def load_scene(path):
+    z = np.load(path, allow_pickle=False)
+    if "format" not in z.files or str(z["format"]) != SCENE_CACHE_FORMAT:
+        raise ValueError(f"{path}: not a {SCENE_CACHE_FORMAT} file")
+    nodes, tris = z["nodes"], z["triangles"]
+    if nodes.dtype != NODE_DTYPE or tris.dtype != TRIANGLE_DTYPE:
+        raise ValueError(f"{path}: unexpected record layout")
+    return {"nodes": nodes, "triangles": tris, "positions": z["positions"],
+            "tex_coords": z["tex_coords"] if "tex_coords" in z.files else None,
+            "normals": z["normals"] if "normals" in z.files else None}
 
 
 class ResourceParser:

@@ -96,6 +96,60 @@ def test_bvh_build_is_deterministic_and_rebuild_is_a_fixed_point():
     assert a.bvh_nodes().tobytes() == b.bvh_nodes().tobytes() and a.triangles().tobytes() == b.triangles().tobytes()
 
 
+@pytest.mark.parametrize("case", ["atrium", "soup200k", "signed_zero_grid", "tiny", "clustered"])
+def test_parallel_bvh_build_is_bit_identical_to_the_serial_build(case):
+    """Row f3: BVHBuilder::build_parallel must reproduce build() bit for bit — nodes (boxes, numbering,
+    leaf ranges) and the triangle permutation — for any thread count, including inputs where the
+    order of min/max reductions could show (signed zeros, duplicates) and unbalanced trees."""
+    rng = np.random.default_rng(11)
+    uv = nrm = None
+    if case == "atrium":
+        tri, pos, uv, nrm, _ = scenes.atrium()
+    elif case == "soup200k":
+        tri, pos, _ = scenes.triangle_soup(200_000, seed=4, extent=50.0)
+    elif case == "signed_zero_grid":
+        # 300 x 300 quads on the z = +-0 plane with x / y coordinates that hit +0 and -0: every box has zero bounds
+        k = 300
+        xs = (np.arange(k + 1, dtype=np.float32) - k // 2)
+        gx, gy = np.meshgrid(xs, xs)
+        pos = np.stack([gx, gy, np.zeros_like(gx)], -1).reshape(-1, 3).astype(np.float32)
+        pos[::3, 2] = -0.0
+        pos[pos[:, 0] == 0, 0] = np.where(np.arange((pos[:, 0] == 0).sum()) % 2 == 0, np.float32(0.0), np.float32(-0.0))
+        idx = np.arange(k * (k + 1)).reshape(k, k + 1)[:, :k].reshape(-1)
+        tri = np.concatenate([np.stack([idx, idx + 1, idx + k + 1, np.zeros_like(idx)], 1),
+                              np.stack([idx + 1, idx + k + 2, idx + k + 1, np.ones_like(idx)], 1)]).astype(np.uint32)
+    elif case == "tiny":
+        tri, pos, _ = scenes.triangle_soup(7, seed=1, extent=2.0)
+    else:  # 95 % of the triangles in a tiny cluster: deep, unbalanced tree; plus exact duplicates
+        tri, pos, _ = scenes.triangle_soup(60_000, seed=8, extent=40.0)
+        pos = pos.copy()
+        pos[: 3 * 57_000] = pos[: 3 * 57_000] * np.float32(1e-3) + np.float32(5.0)
+        pos[3 * 1000: 3 * 2000] = pos[: 3 * 1000]
+        del rng
+    ref = host.Model.from_arrays(tri, pos, uv, nrm)
+    ref.build_bvh()
+    for threads in (2, 5, 8):
+        m = host.Model.from_arrays(tri, pos, uv, nrm)
+        m.build_bvh(threads)
+        assert m.bvh_nodes().tobytes() == ref.bvh_nodes().tobytes(), (case, threads)
+        assert m.triangles().tobytes() == ref.triangles().tobytes(), (case, threads)
+
+
+def test_scene_cache_round_trip(tmp_path):
+    tri, pos, uv, nrm, _ = scenes.atrium()
+    m = host.Model.from_arrays(tri[:5000], pos, uv, nrm)
+    m.build_bvh(4)
+    sc = m.scene_arrays()
+    path = str(tmp_path / "scene.npz")
+    host.save_scene(path, sc)
+    back = host.load_scene(path)
+    for k in ("nodes", "triangles", "positions", "tex_coords", "normals"):
+        assert back[k].dtype == sc[k].dtype and back[k].tobytes() == sc[k].tobytes(), k
+    np.savez(str(tmp_path / "other.npz"), nodes=sc["nodes"])
+    with pytest.raises(ValueError):
+        host.load_scene(str(tmp_path / "other.npz"))
+
+
 def test_obj_quirks():
     text = "\n".join([
         "# comment", "mtllib a.mtl", "v 0 0 0", "v 1 0 0", "v 1 1 0", "v 0 1 0", "  v 9 9 9",   # indented line is ignored
