@@ -35,6 +35,11 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 VALU_PEAK_TOPS = 78.6        # 157.3 TFLOP/s FMA-counted fp32 vector = 78.6 T un-fused op/s
 
 
+WORKLOAD_NOTE = {"atrium_1080p": "procedural Sponza-class atrium", "atrium_small": "procedural Sponza-class atrium",
+                 "soup_10m_4k": "seeded triangle soup (BASELINE config 4)", "soup_1m_4k": "seeded triangle soup",
+                 "bunny_1080p": "bunny subdivided twice (BASELINE config 2)"}
+
+
 def build_workload(name):
     from raytracer_amd import host, scenes
     if name == "atrium_1080p":
@@ -47,6 +52,22 @@ def build_workload(name):
         model = host.Model.from_arrays(tri, pos, uv, nrm)
         w, h = 480, 270
         tex = (scenes.checker_texture(256), scenes.noise_texture(128, 64))
+    elif name == "soup_10m_4k":   # BASELINE config 4 (single-GPU share of it): not the default bench line
+        tri, pos, cam = scenes.triangle_soup(10_000_000)
+        model = host.Model.from_arrays(tri, pos)
+        w, h = 3840, 2160
+        tex = (None, None)
+    elif name == "bunny_1080p":   # BASELINE config 2: bunny (from the committed fixture) subdivided twice, white albedo
+        z = np.load(os.path.join(REPO, "tests", "golden", "golden_bunny.npz"), allow_pickle=False)
+        t = z["triangles"]
+        tri, pos, nrm = scenes.subdivide(np.stack([t["p0"], t["p1"], t["p2"], t["mat_idx"]], 1), z["positions"], z["normals"], levels=2)
+        model = host.Model.from_arrays(tri, pos, None, nrm)
+        w, h = 1920, 1080
+        tex = (None, None)
+        lo, hi = pos.min(0), pos.max(0)
+        c = (lo + hi) / 2
+        eye = c + 0.9 * np.linalg.norm(hi - lo) / 2 * np.float32([0.7, 0.3, 0.65])
+        cam = {"position": tuple(float(x) for x in eye), "direction": tuple(float(x) for x in (c - eye)), "fov_deg": 60.0}
     elif name == "soup_1m_4k":
         tri, pos, cam = scenes.triangle_soup(1_000_000)
         model = host.Model.from_arrays(tri, pos)
@@ -274,7 +295,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: procedural Sponza-class atrium, {len(sc['triangles'])} triangles, "
+        "config": {"workload": f"{args.workload}: {WORKLOAD_NOTE.get(args.workload, 'scene')}, {len(sc['triangles'])} triangles, "
                                f"{W}x{H}, 1 spp, primary + sun shadow ray + shading (fused ray_trace_and_shade semantics)",
                    "rays_per_frame": rays_per_frame, "primary_rays": n_primary_all, "shadow_rays": n_shadow_all,
                    "parallelism": f"tiles{world}" if world > 1 else "single", "kernel_variant": args.variant,
