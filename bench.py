@@ -89,7 +89,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="atrium_1080p")
     ap.add_argument("--variant", type=int, default=0, help="0 persistent (default), 1 static A/B baseline")
-    ap.add_argument("--frames-in-flight", type=int, default=2, help="frames issued on alternating streams (1 = serial)")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frames issued round-robin on that many streams (1 = serial; 0 = auto: 2 on one GPU, 6 with tiles split over "
+                         "several GPUs, where a launch covers 1/N of the frame and is bounded by its slowest rays, not by throughput)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -143,7 +145,8 @@ def main():
 
     per_rank_tiles = tracer.tiles_per_rank(W, H, world)
     n_local_out = n_px if world == 1 else per_rank_tiles * TILE_PIXELS
-    F = max(1, min(4, args.frames_in_flight))
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world == 1 else 6)
+    F = max(1, min(8, F))
     # frame k renders on render_streams[k % F] into rgba[k % F]; gather + assembly stay on `stream`
     render_streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(F - 1)]
     rgba = [torch.zeros((n_local_out, 4), dtype=torch.float32, device=dev) for _ in range(F)]

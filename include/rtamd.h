@@ -76,9 +76,9 @@ const char *rtamd_last_error(const rtamd_context *ctx);
  * last, slowest work items) then runs beside the start of the next, which on MI355X raises
  * the frame rate of the fused shader by about 1.4x.  The context keeps
  * separate launch scratch (queue counters, stack-spill area, timing events) per stream for
- * up to 4 streams, so a caller pipelines frames by alternating two streams of its own:
+ * up to 8 streams, so a caller pipelines frames by alternating two streams of its own:
  *     set_stream(s[k % 2]); rtamd_render_device(..., out[k % 2]);
- * and orders consumers with ordinary stream/event dependencies.  A fifth stream takes over
+ * and orders consumers with ordinary stream/event dependencies.  A ninth stream takes over
  * the least recently used scratch after that one's last launch has finished.  Synchronize a
  * stream before destroying it.  (The reference's passes are serialised by the GL command
  * stream, src/main.rs:143-230; this has no counterpart there.) */

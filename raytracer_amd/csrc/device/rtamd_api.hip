@@ -47,7 +47,7 @@ struct rtamd_context {
         DevBuf item_cost, item_order;
         uint32_t order_items[2] = {0, 0};   // n_items the schedule of mode [fused, trace] is valid for (0 = none yet)
     };
-    static constexpr int MAX_SLOTS = 4;
+    static constexpr int MAX_SLOTS = 8;
     Slot slots[MAX_SLOTS];
     uint64_t use_clock = 0;
     int last_slot = -1;
@@ -147,7 +147,7 @@ int ensure_ctx_device(rtamd_context *ctx) {
     return RTAMD_OK;
 }
 
-constexpr size_t QUEUE_BYTES = 32 * 16384;   // num_queues <= 32, queue_stride <= 4096 words
+constexpr size_t QUEUE_BYTES = 32 * 16384 + 256;   // num_queues <= 32, queue_stride <= 4096 words; + the exit counter
 
 // The scratch slot of the context's current stream (created on first use).
 int acquire_slot(rtamd_context *ctx, rtamd_context::Slot **out) {
@@ -162,7 +162,10 @@ int acquire_slot(rtamd_context *ctx, rtamd_context::Slot **out) {
     int rc;
     if (!sl->ev_start) HIP_TRY(ctx, hipEventCreate(&sl->ev_start));
     if (!sl->ev_stop) HIP_TRY(ctx, hipEventCreate(&sl->ev_stop));
-    if (!sl->queues.p && (rc = dev_alloc(ctx, sl->queues, QUEUE_BYTES))) return rc;
+    if (!sl->queues.p) {
+        if ((rc = dev_alloc(ctx, sl->queues, QUEUE_BYTES))) return rc;
+        HIP_TRY(ctx, hipMemset(sl->queues.p, 0, QUEUE_BYTES));   // once: k_persistent leaves the counters at zero
+    }
     if (!sl->spill.p && (rc = dev_alloc(ctx, sl->spill, ctx->spill_bytes))) return rc;
     sl->key = ctx->stream; sl->bound = true; sl->ev_valid = false;
     sl->order_items[0] = sl->order_items[1] = 0;
@@ -179,6 +182,7 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     if (rc_slot) return rc_slot;
     ctx->last_slot = (int)(sl - ctx->slots);
     p.queues = (uint32_t *)sl->queues.p;
+    p.done = (uint32_t *)sl->queues.p + 32 * 4096;
     p.n_queues = ctx->n_queues;
     p.dyn_thresh = mode == MODE_FUSED ? ctx->dyn_thresh_fused : ctx->dyn_thresh_trace;
     p.leaf_thresh = ctx->leaf_thresh;
@@ -205,7 +209,6 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
 #endif
     hipStream_t st = ctx->stream;
     const SceneDev &s = ctx->sdev;
-    if (ctx->variant == 0) HIP_TRY(ctx, hipMemsetAsync(sl->queues.p, 0, (size_t)ctx->n_queues * ctx->queue_stride * sizeof(uint32_t), st));
     HIP_TRY(ctx, hipEventRecord(sl->ev_start, st));
     if (ctx->variant == 0) {
         int per_cu = ctx->persistent_blocks_per_cu[mode * 2 + (count ? 1 : 0)];

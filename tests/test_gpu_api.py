@@ -228,8 +228,8 @@ def test_soup_incoherent_trace_matches_oracle(tracer, oracle_a):
 
 def test_frames_in_flight_on_several_streams(tracer, atrium):
     """Launches issued on different streams overlap (frames in flight): each stream has its
-    own launch scratch in the context, a seventh stream takes over the least recently used
-    one.  Every frame must equal the frame rendered alone on the context's own stream."""
+    own launch scratch in the context (8 sets), a further stream takes over the least recently
+    used one.  Every frame must equal the frame rendered alone on the context's own stream."""
     import torch
     sc, camera, tex = atrium
     W, H = 640, 360
@@ -243,16 +243,16 @@ def test_frames_in_flight_on_several_streams(tracer, atrium):
     tracer.render_device(W, H, camera=(inv, camera.position), has_tex_coords=True, has_normals=True, rgba_ptr=alone.data_ptr())
     tracer.synchronize()
     assert float(alone[:, 3].min()) == 1.0
-    streams = [torch.cuda.Stream(device=dev) for _ in range(6)]
-    outs = [torch.zeros((n, 4), dtype=torch.float32, device=dev) for _ in range(6)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(10)]
+    outs = [torch.zeros((n, 4), dtype=torch.float32, device=dev) for _ in range(10)]
     try:
         for rnd in range(3):
             for o in outs:
                 o.zero_()
             torch.cuda.synchronize()
-            for k in range(12):
-                tracer.set_stream(streams[k % 6].cuda_stream)
-                tracer.render_device(W, H, camera=(inv, camera.position), has_tex_coords=True, has_normals=True, rgba_ptr=outs[k % 6].data_ptr())
+            for k in range(20):
+                tracer.set_stream(streams[k % 10].cuda_stream)
+                tracer.render_device(W, H, camera=(inv, camera.position), has_tex_coords=True, has_normals=True, rgba_ptr=outs[k % 10].data_ptr())
             torch.cuda.synchronize()
             for o in outs:
                 assert torch.equal(o.view(torch.int32), alone.view(torch.int32))
@@ -276,6 +276,8 @@ def test_full_size_soup_10m_4k(tracer, oracle_a):
     del m
     assert len(sc["triangles"]) == 10_000_000
     tracer.upload_scene(sc)
+    white = np.full((1, 1, 3), 255, np.uint8)      # the tracer fixture is shared: earlier tests left their albedo textures
+    tracer.upload_texture(0, white); tracer.upload_texture(1, white)
     W, H = 3840, 2160
     camera = host.Camera(W / H, fov=math.radians(cam["fov_deg"]), position=cam["position"], direction=cam["direction"])
     inv = camera.inv_proj_view()

@@ -1,0 +1,26 @@
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.getcwd())
+import torch, bench
+from raytracer_amd.renderer import HipRayTracer
+model, camera, W, H, tex = bench.build_workload("atrium_1080p")
+sc = model.scene_arrays(); dev = torch.device("cuda", 0)
+tr = HipRayTracer(0); tr.upload_scene(sc)
+for slot, t in enumerate(tex): tr.upload_texture(slot, t)
+n = W * H
+d_dir = torch.empty((n, 3), dtype=torch.float32, device=dev); tr.generate_rays_device(W, H, camera.inv_proj_view(), d_dir.data_ptr())
+d_org = torch.tensor(np.asarray(camera.position, np.float32), device=dev).repeat(n, 1).contiguous()
+streams = [torch.cuda.Stream(device=dev) for _ in range(8)]
+for world in (1, 2, 4, 8):
+    per = tr.tiles_per_rank(W, H, world) * 1024
+    outs = [torch.zeros((per if world > 1 else n, 4), dtype=torch.float32, device=dev) for _ in range(8)]
+    for S in (1, 2, 6):
+        K = 400
+        for rep in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for k in range(K):
+                tr.set_stream(streams[k % S].cuda_stream)
+                tr.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=True, has_normals=True, tile_rank=3 % world, tile_world=world, rgba_ptr=outs[k % S].data_ptr())
+            t_cpu = time.perf_counter() - t0
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"tile_world {world} streams {S}: {dt / K * 1e6:.1f} us per frame (CPU issue {t_cpu / K * 1e6:.1f} us), last kernel {tr.last_kernel_ms()*1e3:.1f} us", flush=True)
