@@ -27,6 +27,22 @@ typedef struct rtamd_model rtamd_model;
  * (ResourceError::ResourceParseError, src/util/error.rs:24-33). */
 int rtamd_model_parse_obj(const char *data, size_t len, rtamd_model **out, char *err, size_t err_len);
 
+/* ---- material libraries: ResourceParser::parse_material_lib (resource_parser.rs:49-109),
+ * Material / MaterialLibBuilder (src/rendering/material.rs:5-116); SURVEY section 8 row f4 ---- */
+typedef struct rtamd_material_lib rtamd_material_lib;
+typedef struct rtamd_material {
+    const char *name;                       /* newmtl name; borrowed, valid until the library is freed */
+    float ambient_color[3], diffuse_color[3], specular_color[3], transmission_color[3];   /* Ka Kd Ks Tf; defaults 0.3 / 1 / 1 / 1 */
+    float specular_exp, transmission, optical_density;                                    /* Ns (10), Tr or 1 - d (0), Ni (1) */
+    const char *ambient_tex, *diffuse_tex, *specular_tex, *specular_exp_tex;              /* map_Ka/Kd/Ks/Ns or NULL (Option::None) */
+} rtamd_material;
+/* Returns 0, or -(kind+1) with a "Kind at line N: detail" message in err (kinds as for
+ * rtamd_model_parse_obj, plus NoMaterialNamed = a property before the first newmtl). */
+int rtamd_material_lib_parse(const char *data, size_t len, rtamd_material_lib **out, char *err, size_t err_len);
+void rtamd_material_lib_free(rtamd_material_lib *lib);
+uint32_t rtamd_material_lib_count(const rtamd_material_lib *lib);
+int rtamd_material_lib_get(const rtamd_material_lib *lib, uint32_t index, rtamd_material *out);
+
 /* A model straight from arrays (synthetic scenes): triangles are 16-byte
  * (p0,p1,p2,mat_idx) records; tex_coords / normals may be NULL. */
 int rtamd_model_from_arrays(const void *triangles, uint32_t triangle_count, const float *positions, uint32_t vertex_count,
@@ -57,6 +73,8 @@ const float *rtamd_model_normals(const rtamd_model *m);
 const void *rtamd_model_bvh_nodes(const rtamd_model *m);
 /* Material name for mat_idx i in first-`usemtl` order (model.rs:89-97,136-137). */
 const char *rtamd_model_material_name(const rtamd_model *m, uint32_t i);
+/* i-th `mtllib` file name in file order (model.rs:85-87), NULL past the end. */
+const char *rtamd_model_material_lib_name(const rtamd_model *m, uint32_t i);
 
 /* Camera::view_proj_matrices (src/rendering/camera.rs:75-82) and the inverse of
  * proj*view that src/main.rs:149 uploads; all matrices column-major float[16].

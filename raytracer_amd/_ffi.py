@@ -26,6 +26,15 @@ class ModelInfo(ctypes.Structure):
         "has_tex_coords", "has_normals", "has_bvh")]
 
 
+class MaterialRec(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p),
+                ("ambient_color", ctypes.c_float * 3), ("diffuse_color", ctypes.c_float * 3),
+                ("specular_color", ctypes.c_float * 3), ("transmission_color", ctypes.c_float * 3),
+                ("specular_exp", ctypes.c_float), ("transmission", ctypes.c_float), ("optical_density", ctypes.c_float),
+                ("ambient_tex", ctypes.c_char_p), ("diffuse_tex", ctypes.c_char_p),
+                ("specular_tex", ctypes.c_char_p), ("specular_exp_tex", ctypes.c_char_p)]
+
+
 class SceneDesc(ctypes.Structure):
     _fields_ = [
         ("nodes", ctypes.c_void_p), ("node_count", ctypes.c_uint32),
@@ -97,6 +106,14 @@ def host_lib():
         L.rtamd_model_build_bvh.restype = ctypes.c_int
         L.rtamd_model_build_bvh_parallel.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
         L.rtamd_model_build_bvh_parallel.restype = ctypes.c_int
+        L.rtamd_material_lib_parse.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.c_char_p, ctypes.c_size_t]
+        L.rtamd_material_lib_parse.restype = ctypes.c_int
+        L.rtamd_material_lib_free.argtypes = [ctypes.c_void_p]
+        L.rtamd_material_lib_free.restype = None
+        L.rtamd_material_lib_count.argtypes = [ctypes.c_void_p]
+        L.rtamd_material_lib_count.restype = ctypes.c_uint32
+        L.rtamd_material_lib_get.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(MaterialRec)]
+        L.rtamd_material_lib_get.restype = ctypes.c_int
         L.rtamd_model_get_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ModelInfo)]
         L.rtamd_model_get_info.restype = None
         for name in ("rtamd_model_triangles", "rtamd_model_positions", "rtamd_model_tex_coords",
@@ -105,6 +122,8 @@ def host_lib():
             getattr(L, name).restype = ctypes.c_void_p
         L.rtamd_model_material_name.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
         L.rtamd_model_material_name.restype = ctypes.c_char_p
+        L.rtamd_model_material_lib_name.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+        L.rtamd_model_material_lib_name.restype = ctypes.c_char_p
         L.rtamd_camera_matrices.argtypes = [ctypes.c_float, ctypes.c_float, c_float_p, c_float_p, c_float_p,
                                             c_float_p, c_float_p, c_float_p]
         L.rtamd_camera_matrices.restype = ctypes.c_int

@@ -13,6 +13,7 @@
 using namespace rtamd::host;
 
 struct rtamd_model { Model model; };
+struct rtamd_material_lib { std::vector<std::pair<std::string, Material>> materials; };
 
 static const char *kind_name(ParseErrorKind k) {
     switch (k) {
@@ -20,6 +21,7 @@ static const char *kind_name(ParseErrorKind k) {
         case ParseErrorKind::ParseFloatError: return "ParseFloatError";
         case ParseErrorKind::InvalidLineArgCount: return "InvalidLineArgCount";
         case ParseErrorKind::IndexOutOfRange: return "IndexOutOfRange";
+        case ParseErrorKind::NoMaterialNamed: return "NoMaterialNamed";
         default: return "None";
     }
 }
@@ -42,6 +44,42 @@ int rtamd_model_parse_obj(const char *data, size_t len, rtamd_model **out, char 
         if (err && err_len) std::snprintf(err, err_len, "exception: %s", ex.what());
         return -100;
     }
+}
+
+int rtamd_material_lib_parse(const char *data, size_t len, rtamd_material_lib **out, char *err, size_t err_len) {
+    if (err && err_len) err[0] = 0;
+    if (!data || !out) return -1;
+    try {
+        ParseError e;
+        auto mats = ResourceParser::parse_material_lib(std::string(data, len), &e);
+        if (e) {
+            if (err && err_len) std::snprintf(err, err_len, "%s at line %u: %s", kind_name(e.kind), e.line, e.detail.c_str());
+            return -(int)e.kind - 1;
+        }
+        *out = new rtamd_material_lib{std::move(mats)};
+        return 0;
+    } catch (const std::exception &ex) {
+        if (err && err_len) std::snprintf(err, err_len, "exception: %s", ex.what());
+        return -100;
+    }
+}
+
+void rtamd_material_lib_free(rtamd_material_lib *lib) { delete lib; }
+uint32_t rtamd_material_lib_count(const rtamd_material_lib *lib) { return lib ? (uint32_t)lib->materials.size() : 0; }
+
+int rtamd_material_lib_get(const rtamd_material_lib *lib, uint32_t index, rtamd_material *out) {
+    if (!lib || !out || index >= lib->materials.size()) return -1;
+    const Material &m = lib->materials[index].second;
+    out->name = lib->materials[index].first.c_str();
+    const Vec3 *src[4] = {&m.ambient_color, &m.diffuse_color, &m.specular_color, &m.transmission_color};
+    float *dst[4] = {out->ambient_color, out->diffuse_color, out->specular_color, out->transmission_color};
+    for (int k = 0; k < 4; k++) { dst[k][0] = src[k]->x; dst[k][1] = src[k]->y; dst[k][2] = src[k]->z; }
+    out->specular_exp = m.specular_exp; out->transmission = m.transmission; out->optical_density = m.optical_density;
+    out->ambient_tex = m.has_ambient_tex ? m.ambient_tex.c_str() : nullptr;
+    out->diffuse_tex = m.has_diffuse_tex ? m.diffuse_tex.c_str() : nullptr;
+    out->specular_tex = m.has_specular_tex ? m.specular_tex.c_str() : nullptr;
+    out->specular_exp_tex = m.has_specular_exp_tex ? m.specular_exp_tex.c_str() : nullptr;
+    return 0;
 }
 
 int rtamd_model_from_arrays(const void *triangles, uint32_t triangle_count, const float *positions, uint32_t vertex_count,
@@ -110,6 +148,10 @@ const float *rtamd_model_normals(const rtamd_model *m) {
 const void *rtamd_model_bvh_nodes(const rtamd_model *m) { return m && m->model.get_bvh() ? m->model.get_bvh()->data().data() : nullptr; }
 const char *rtamd_model_material_name(const rtamd_model *m, uint32_t i) {
     return m && i < m->model.get_materials().size() ? m->model.get_materials()[i].c_str() : nullptr;
+}
+
+const char *rtamd_model_material_lib_name(const rtamd_model *m, uint32_t i) {
+    return m && i < m->model.get_material_libs().size() ? m->model.get_material_libs()[i].c_str() : nullptr;
 }
 
 int rtamd_camera_matrices(float aspect, float fov_rad, const float position[3], const float up[3], const float direction[3],

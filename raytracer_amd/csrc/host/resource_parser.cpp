@@ -194,5 +194,87 @@ Model ResourceParser::parse_model(const std::string &data, ParseError *err) {
     return m;
 }
 
+std::vector<std::pair<std::string, Material>> ResourceParser::parse_material_lib(const std::string &data, ParseError *err) {
+    MaterialLibBuilder lb;
+    std::vector<Tok> toks;
+    ParseError e;
+    uint32_t line_no = 0;
+    size_t pos = 0;
+    const size_t n = data.size();
+    auto need_current = [&](Material **m) {
+        *m = lb.current();
+        if (*m) return true;
+        e.kind = ParseErrorKind::NoMaterialNamed;
+        e.detail = "property before the first newmtl";
+        return false;
+    };
+    struct ColorProp { const char *prefix; Vec3 Material::*field; };
+    static const ColorProp colors[] = {{"Ka ", &Material::ambient_color}, {"Kd ", &Material::diffuse_color},
+                                       {"Ks ", &Material::specular_color}, {"Tf ", &Material::transmission_color}};
+    struct TexProp { const char *prefix; std::string Material::*name; bool Material::*has; };
+    static const TexProp texes[] = {{"map_Ka ", &Material::ambient_tex, &Material::has_ambient_tex},
+                                    {"map_Kd ", &Material::diffuse_tex, &Material::has_diffuse_tex},
+                                    {"map_Ks ", &Material::specular_tex, &Material::has_specular_tex},
+                                    {"map_Ns ", &Material::specular_exp_tex, &Material::has_specular_exp_tex}};
+    while (pos <= n && !e) {
+        size_t nl = data.find('\n', pos);
+        if (nl == std::string::npos) nl = n;
+        Tok line{data.data() + pos, nl - pos};
+        line_no++;
+        pos = nl + 1;
+        float vals[8];
+        Material *m = nullptr;
+        if (starts_with(line, "newmtl ")) {
+            std::string v;
+            if ((e = parse_string_line(line, toks, &v))) break;
+            lb.add_material(v);
+        }
+        for (const ColorProp &c : colors) {
+            if (!starts_with(line, c.prefix)) continue;
+            if ((e = parse_values(line, 3, 3, toks, vals))) break;
+            if (!need_current(&m)) break;
+            m->*(c.field) = Vec3{vals[0], vals[1], vals[2]};
+        }
+        if (e) break;
+        if (starts_with(line, "Ns ")) {
+            if ((e = parse_values(line, 1, 1, toks, vals))) break;
+            if (!need_current(&m)) break;
+            m->specular_exp = vals[0];
+        }
+        if (starts_with(line, "d ")) {
+            if ((e = parse_values(line, 1, 1, toks, vals))) break;
+            if (!need_current(&m)) break;
+            m->transmission = 1.0f - vals[0];   // resource_parser.rs:78
+        }
+        if (starts_with(line, "Tr ")) {
+            if ((e = parse_values(line, 1, 1, toks, vals))) break;
+            if (!need_current(&m)) break;
+            m->transmission = vals[0];
+        }
+        if (starts_with(line, "Ni ")) {
+            if ((e = parse_values(line, 1, 1, toks, vals))) break;
+            if (!need_current(&m)) break;
+            m->optical_density = vals[0];
+        }
+        for (const TexProp &t : texes) {
+            if (!starts_with(line, t.prefix)) continue;
+            std::string v;
+            if ((e = parse_string_line(line, toks, &v))) break;
+            if (!need_current(&m)) break;
+            m->*(t.name) = v;
+            m->*(t.has) = true;
+        }
+        if (e) break;
+        if (nl == n) break;
+    }
+    if (e) {
+        e.line = line_no;
+        if (err) *err = e;
+        return {};
+    }
+    if (err) *err = ParseError();
+    return lb.build();
+}
+
 }  // namespace host
 }  // namespace rtamd

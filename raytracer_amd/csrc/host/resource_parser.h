@@ -15,6 +15,7 @@
 #pragma once
 #include <string>
 
+#include "material.h"
 #include "model.h"
 
 namespace rtamd {
@@ -24,6 +25,11 @@ class ResourceParser {
 public:
     // On failure returns an empty model and fills `err` (line is 1-based).
     static Model parse_model(const std::string &data, ParseError *err);
+    // resource_parser.rs:49-109: "newmtl", "Ka", "Kd", "Ks", "Tf" (3 values), "Ns", "d" (stored as
+    // transmission = 1 - d), "Tr", "Ni" (1 value), "map_Ka/Kd/Ks/Ns" (one name); lines are matched by
+    // literal prefix at column 0 and everything else is ignored; a property before the first
+    // `newmtl` is the NoMaterialNamed error.  Materials are returned in file order.
+    static std::vector<std::pair<std::string, Material>> parse_material_lib(const std::string &data, ParseError *err);
 };
 
 }  // namespace host

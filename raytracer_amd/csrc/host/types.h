@@ -94,7 +94,7 @@ struct IndexBundle {  // types.rs:147-181
 };
 
 // Error convention: mirrors util/error.rs:17-33 as (kind, message, line).
-enum class ParseErrorKind { None = 0, ParseIntError, ParseFloatError, InvalidLineArgCount, IndexOutOfRange };
+enum class ParseErrorKind { None = 0, ParseIntError, ParseFloatError, InvalidLineArgCount, IndexOutOfRange, NoMaterialNamed };
 struct ParseError {
     ParseErrorKind kind = ParseErrorKind::None;
     std::string detail;

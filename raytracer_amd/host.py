@@ -104,6 +104,15 @@ class Model:
     def materials(self):
         return [self._lib.rtamd_model_material_name(self._h, i).decode() for i in range(self.info().material_count)]
 
+    def material_libs(self):
+        out, i = [], 0
+        while True:
+            n = self._lib.rtamd_model_material_lib_name(self._h, i)
+            if n is None:
+                return out
+            out.append(n.decode())
+            i += 1
+
     def scene_arrays(self):
         """The five upload slices of src/main.rs:93-102 as a dict of numpy arrays."""
         nodes = self.bvh_nodes()
@@ -154,6 +163,34 @@ class ResourceParser:
         if rc != 0:
             raise ResourceParseError(err.value.decode(errors="replace"))
         return Model(out.value)
+
+
+    @staticmethod
+    def parse_material_lib(data):
+        """resource_parser.rs:49-109 -> list of (name, dict) in file order; dict keys follow material.rs:5-21,
+        texture entries are None when the Option is None."""
+        if isinstance(data, str):
+            data = data.encode("utf-8")
+        lib = _ffi.host_lib()
+        out = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(1024)
+        rc = lib.rtamd_material_lib_parse(data, len(data), ctypes.byref(out), err, len(err))
+        if rc != 0:
+            raise ResourceParseError(err.value.decode(errors="replace"))
+        try:
+            mats = []
+            for i in range(lib.rtamd_material_lib_count(out)):
+                r = _ffi.MaterialRec()
+                lib.rtamd_material_lib_get(out, i, ctypes.byref(r))
+                d = {k: tuple(getattr(r, k)) for k in ("ambient_color", "diffuse_color", "specular_color", "transmission_color")}
+                d.update({k: getattr(r, k) for k in ("specular_exp", "transmission", "optical_density")})
+                d.update({k: (getattr(r, k).decode() if getattr(r, k) is not None else None)
+                          for k in ("ambient_tex", "diffuse_tex", "specular_tex", "specular_exp_tex")})
+                d["texture_names"] = [d[k] for k in ("ambient_tex", "diffuse_tex", "specular_tex", "specular_exp_tex") if d[k] is not None]
+                mats.append((r.name.decode(), d))
+            return mats
+        finally:
+            lib.rtamd_material_lib_free(out)
 
 
 class Camera:

@@ -1,0 +1,96 @@
+"""Row f4 (asset layer): MTL parsing with the reference's rules (resource_parser.rs:49-109, material.rs:5-116),
+OBJ + MTL + image loading into the upload arrays, and the frame writer that stands in for display.frag."""
+import numpy as np
+import pytest
+
+from raytracer_amd import assets, host
+
+MTL = """# comment
+newmtl hull
+Ka 0.1 0.2 0.3
+Kd 0.5 0.25 1
+Ks 1 1 1
+Tf 0.9 0.8 0.7
+Ns 16
+d 0.25
+Ni 1.5
+map_Kd  hull.ppm
+map_Ka amb.png
+newmtl glass
+Tr 0.75
+map_Ks s.png
+map_Ns n.png
+illum 2
+   Kd 9 9 9
+"""
+
+
+def test_material_lib_fields_defaults_and_order():
+    mats = host.ResourceParser.parse_material_lib(MTL)
+    assert [n for n, _ in mats] == ["hull", "glass"]
+    hull, glass = mats[0][1], mats[1][1]
+    assert hull["ambient_color"] == tuple(np.float32([0.1, 0.2, 0.3]).tolist())
+    assert hull["diffuse_color"] == (0.5, 0.25, 1.0) and hull["transmission_color"] == tuple(np.float32([0.9, 0.8, 0.7]).tolist())
+    assert hull["specular_exp"] == 16.0 and hull["optical_density"] == 1.5
+    assert hull["transmission"] == 0.75                      # d 0.25 is stored as 1 - d (resource_parser.rs:78)
+    assert hull["diffuse_tex"] == "hull.ppm" and hull["ambient_tex"] == "amb.png" and hull["specular_tex"] is None
+    assert hull["texture_names"] == ["amb.png", "hull.ppm"]  # ambient, diffuse, specular, specular_exp order (material.rs:40-47)
+    # defaults of Material::default (material.rs:24-38); the indented "   Kd" line does not start with "Kd " and is ignored
+    assert glass["ambient_color"] == tuple(np.float32([0.3] * 3).tolist()) and glass["diffuse_color"] == (1.0, 1.0, 1.0)
+    assert glass["specular_exp"] == 10.0 and glass["optical_density"] == 1.0 and glass["transmission"] == 0.75
+    assert glass["texture_names"] == ["s.png", "n.png"]
+
+
+@pytest.mark.parametrize("text,kind,line", [
+    ("Ka 1 2 3\n", "NoMaterialNamed", 1),                       # material.rs:62-64
+    ("newmtl a\nKd 1 2\n", "InvalidLineArgCount", 2),
+    ("newmtl a b\n", "InvalidLineArgCount", 1),
+    ("newmtl a\n\nNs x\n", "ParseFloatError", 3),               # the reference panics here (unwrap)
+    ("newmtl a\nmap_Kd\n", None, 0),                             # "map_Kd" without the trailing space is not a map_Kd line
+])
+def test_material_lib_errors(text, kind, line):
+    if kind is None:
+        assert host.ResourceParser.parse_material_lib(text)[0][1]["diffuse_tex"] is None
+        return
+    with pytest.raises(host.ResourceParseError) as e:
+        host.ResourceParser.parse_material_lib(text)
+    assert kind in str(e.value) and f"line {line}" in str(e.value)
+
+
+def test_frame_writer_matches_unorm8_back_buffer(tmp_path):
+    w, h = 5, 3
+    frame = np.zeros((h, w, 4), np.float32)
+    frame[0, :, 0] = [-1.0, 0.0, 0.5, 1.0, 7.0]     # bottom row: clamp below / above
+    frame[2, :, 1] = [0.499 / 255, 0.501 / 255, 254.5 / 255, np.nan, np.inf]
+    frame[..., 3] = 1.0
+    img = assets.frame_to_rgb8(frame.reshape(-1, 4), w, h)
+    assert img.shape == (h, w, 3)
+    assert img[2, :, 0].tolist() == [0, 0, 128, 255, 255]          # bottom row of the frame is the last image row
+    assert img[0, :, 1].tolist() == [0, 1, 254, 0, 255]            # round to nearest (254.5 -> 254: ties to even)
+    path = str(tmp_path / "f.ppm")
+    assets.write_ppm(path, frame, w, h)
+    assert np.array_equal(assets.load_image_rgb8(path), img)
+    assets.write_png(str(tmp_path / "f.png"), frame, w, h)
+    assert np.array_equal(assets.load_image_rgb8(str(tmp_path / "f.png")), img)
+
+
+def test_load_obj_scene_with_materials_and_textures(tmp_path):
+    rng = np.random.default_rng(0)
+    tex0 = rng.integers(0, 256, (4, 6, 3), dtype=np.uint8)
+    tex1 = rng.integers(0, 256, (2, 2, 3), dtype=np.uint8)
+    from PIL import Image
+    Image.fromarray(tex0, "RGB").save(str(tmp_path / "a.bmp"))
+    (tmp_path / "tex").mkdir()
+    with open(tmp_path / "tex" / "b.ppm", "wb") as f:
+        f.write(b"P6\n# made by the test\n2 2\n255\n" + tex1.tobytes())
+    (tmp_path / "m.mtl").write_text("newmtl second\nmap_Kd b.ppm\nnewmtl first\nmap_Kd a.bmp\nnewmtl third\nmap_Kd c.png\n")
+    (tmp_path / "s.obj").write_text(
+        "mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nvt 0 0\nvt 1 0\nvt 0 1\n"
+        "usemtl first\nf 1/1 2/2 3/3\nusemtl second\nf 1/1 2/2 4/3\nusemtl third\nf 1/1 3/2 4/3\nusemtl nowhere\nf 2/1 3/2 4/3\n")
+    r = assets.load_obj_scene(str(tmp_path / "s.obj"), texture_dirs=[str(tmp_path / "tex")], bvh_threads=2)
+    assert [n for n, _ in r["materials"]] == ["first", "second", "third", "nowhere"]     # first-usemtl order = mat_idx
+    assert np.array_equal(r["textures"][0], tex0) and np.array_equal(r["textures"][1], tex1)
+    assert sorted(r["scene"]["triangles"]["mat_idx"].tolist()) == [0, 1, 2, 3]
+    assert r["scene"]["tex_coords"] is not None and len(r["scene"]["nodes"]) >= 2
+    w = "\n".join(r["warnings"])
+    assert "third" in w and "modelTextures[2]" in w and "nowhere" in w and "not defined" in w
