@@ -181,6 +181,24 @@ int rtamd_generate_rays(rtamd_context *ctx, uint32_t width, uint32_t height, con
 int rtamd_generate_rays_device(rtamd_context *ctx, uint32_t width, uint32_t height, const float inv_proj_view[16],
                                float near_plane, float far_plane, float *dir_out);
 
+/* As rtamd_generate_rays_device with the sample at (offset_x, offset_y) inside each pixel instead of the
+ * centre (0.5, 0.5): jittered primaries for multi-sample frames (BASELINE config 5).  No counterpart in
+ * the reference, which rasterises one sample per pixel. */
+int rtamd_generate_rays_offset_device(rtamd_context *ctx, uint32_t width, uint32_t height, const float inv_proj_view[16],
+                                      float near_plane, float far_plane, float offset_x, float offset_y, float *dir_out);
+
+/* ---- hit records -> G-buffer ------------------------------------------------ */
+
+/* For ray i with hit record hits[4i..] = (t, u, v, bits(idx)) (rtamd_trace): position[3i..] = org + dir * t,
+ * normal_mat[4i..] = (triangleNormal(idx, uv) (ray_trace_and_shade.frag:165-178), bits(mat_idx)); a miss or
+ * NO_RAY record (t = 1e30) gives position 0 and normal_mat (0,0,0,1e30), the G-buffer's "no surface" value
+ * (src/main.rs:130).  This is the input rtamd_dispatch_rays takes: the reference fills it with its rasteriser
+ * pass (src/main.rs:127-140) and therefore stops at one bounce; with this, dispatcher -> trace can repeat. */
+int rtamd_surface_from_hits(rtamd_context *ctx, uint64_t n, const float *org, const float *dir, const float *hits, uint32_t has_normals,
+                            float *position, float *normal_mat);
+int rtamd_surface_from_hits_device(rtamd_context *ctx, uint64_t n, const float *org, const float *dir, const float *hits, uint32_t has_normals,
+                                   float *position, float *normal_mat);
+
 /* ---- secondary-ray generation: ray_trace/ray_dispatcher.frag:26-41 ---------- */
 
 /* The blue-noise texture (uniform location 2, res/textures/blue_noise.png via

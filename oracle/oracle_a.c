@@ -465,3 +465,30 @@ void oa_dispatch(uint32_t w, uint32_t h, const float *position, const float *nor
     }
     _mm_setcsr(csr);
 }
+
+/* Hit records (t,u,v,bits(idx)) of ray_trace.frag -> the G-buffer texels the dispatcher reads
+ * (what the reference's rasteriser pass writes, src/main.rs:127-140, restated for ray hits):
+ * position = org + dir * t, normal = triangleNormal (ray_trace_and_shade.frag:165-178),
+ * w = bits(mat_idx), or position 0 / (0,0,0,1e30) for a miss or NO_RAY record. */
+void oa_surface_from_hits(const oa_scene *sc, uint64_t n, const float *org, const float *dir, const float *hits, int has_normals,
+                          float *position, float *normal_mat) {
+    unsigned csr = _mm_getcsr();
+    apply_fp_mode();
+    for (uint64_t i = 0; i < n; i++) {
+        const float *h = hits + 4 * i;
+        float *p = position + 3 * i, *nm = normal_mat + 4 * i;
+        if (!(h[0] < OA_MISS)) {
+            p[0] = p[1] = p[2] = 0.0f;
+            nm[0] = nm[1] = nm[2] = 0.0f; nm[3] = OA_MISS;
+            continue;
+        }
+        uint32_t idx;
+        memcpy(&idx, &h[3], 4);
+        v2 uv = { h[1], h[2] };
+        v3 nrm = oa_tri_normal(sc, has_normals, idx, uv);
+        for (int k = 0; k < 3; k++) p[k] = org[3 * i + k] + dir[3 * i + k] * h[0];
+        nm[0] = nrm.x; nm[1] = nrm.y; nm[2] = nrm.z;
+        memcpy(&nm[3], &sc->triangles[idx].mat, 4);
+    }
+    _mm_setcsr(csr);
+}

@@ -167,6 +167,12 @@ def device_lib():
         for name in ("rtamd_generate_rays", "rtamd_generate_rays_device"):
             getattr(L, name).argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, c_float_p, ctypes.c_float, ctypes.c_float, vp]
             getattr(L, name).restype = ctypes.c_int
+        for name in ("rtamd_surface_from_hits", "rtamd_surface_from_hits_device"):
+            getattr(L, name).argtypes = [vp, ctypes.c_uint64, vp, vp, vp, ctypes.c_uint32, vp, vp]
+            getattr(L, name).restype = ctypes.c_int
+        L.rtamd_generate_rays_offset_device.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, c_float_p, ctypes.c_float, ctypes.c_float,
+                                                        ctypes.c_float, ctypes.c_float, vp]
+        L.rtamd_generate_rays_offset_device.restype = ctypes.c_int
         L.rtamd_upload_noise_texture.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint32]
         L.rtamd_upload_noise_texture.restype = ctypes.c_int
         for name in ("rtamd_dispatch_rays", "rtamd_dispatch_rays_device"):

@@ -474,10 +474,11 @@ __device__ __forceinline__ void shade_primary(const SceneDev &s, const JobParams
 }
 
 // ray_create.frag:12 at the centre of pixel (px,py); row 0 = bottom.
+// (off_x, off_y) is the sample position inside the pixel; (0.5, 0.5) = the pixel centre the reference rasterises.
 __device__ __forceinline__ void gen_primary_dir(const float *__restrict__ m, float near_, float far_, uint32_t width, uint32_t height,
-                                                uint32_t px, uint32_t py, float &dx, float &dy, float &dz) {
-    float x = ((float)px + 0.5f) / (float)width * 2.0f - 1.0f;
-    float y = ((float)py + 0.5f) / (float)height * 2.0f - 1.0f;
+                                                uint32_t px, uint32_t py, float &dx, float &dy, float &dz, float off_x = 0.5f, float off_y = 0.5f) {
+    float x = ((float)px + off_x) / (float)width * 2.0f - 1.0f;
+    float y = ((float)py + off_y) / (float)height * 2.0f - 1.0f;
     float v0 = x * far_ - x * near_;
     float v1 = y * far_ - y * near_;
     float v2 = 1.0f * far_ - (-1.0f) * near_;
@@ -878,7 +879,8 @@ __global__ void __launch_bounds__(BLOCK) k_static(const SceneDev s, const JobPar
 // ---------------------------------------------------------------------------
 // small utility kernels
 // ---------------------------------------------------------------------------
-__global__ void k_generate_rays(const float *__restrict__ ipv16, float near_, float far_, uint32_t width, uint32_t height, float *__restrict__ dir_out) {
+__global__ void k_generate_rays(const float *__restrict__ ipv16, float near_, float far_, uint32_t width, uint32_t height, float off_x, float off_y,
+                                float *__restrict__ dir_out) {
     __shared__ float m[16];
     if (threadIdx.x < 16) m[threadIdx.x] = ipv16[threadIdx.x];
     __syncthreads();
@@ -886,8 +888,45 @@ __global__ void k_generate_rays(const float *__restrict__ ipv16, float near_, fl
     if (i >= width * height) return;
     uint32_t px = i % width, py = i / width;
     float dx, dy, dz;
-    gen_primary_dir(m, near_, far_, width, height, px, py, dx, dy, dz);
+    gen_primary_dir(m, near_, far_, width, height, px, py, dx, dy, dz, off_x, off_y);
     dir_out[3 * (size_t)i + 0] = dx; dir_out[3 * (size_t)i + 1] = dy; dir_out[3 * (size_t)i + 2] = dz;
+}
+
+// Hit records -> the G-buffer the dispatcher reads, for bounces the rasteriser cannot provide
+// (the reference fills positionData / normalMatData with its rasteriser pass, src/main.rs:127-140,
+// so it has one bounce; this is that pass restated for ray hits): position = org + dir * t,
+// normal = triangleNormal(idx, uv) (ray_trace_and_shade.frag:165-178), w = the triangle's material
+// index as bits, or 1e30 ("no surface", main.rs:130) for a miss or a NO_RAY record.
+__global__ void __launch_bounds__(256) k_surface_from_hits(const SceneDev s, uint64_t n, const float *__restrict__ org, const float *__restrict__ dir,
+                                                           const float *__restrict__ hits, uint32_t has_n, float *__restrict__ position, float *__restrict__ normal_mat) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 h = reinterpret_cast<const float4 *>(hits)[i];
+    float px = 0.0f, py = 0.0f, pz = 0.0f;
+    float4 nm = make_float4(0.0f, 0.0f, 0.0f, MISS);
+    if (h.x < MISS) {
+        const uint32_t idx = __float_as_uint(h.w);
+        const float u = h.y, v = h.z;
+        px = org[3 * i] + dir[3 * i] * h.x; py = org[3 * i + 1] + dir[3 * i + 1] * h.x; pz = org[3 * i + 2] + dir[3 * i + 2] * h.x;
+        const RefTriangle tri = s.tri_idx[idx];
+        float nx, ny, nz;
+        if (has_n) {
+            const float w = 1.0f - u - v;
+            const float *n0 = s.normals + 3 * (size_t)tri.p0, *n1 = s.normals + 3 * (size_t)tri.p1, *n2 = s.normals + 3 * (size_t)tri.p2;
+            nx = (n1[0] * u + n2[0] * v) + n0[0] * w;
+            ny = (n1[1] * u + n2[1] * v) + n0[1] * w;
+            nz = (n1[2] * u + n2[2] * v) + n0[2] * w;
+        } else {
+            const TriRecord &rec = s.tris[idx];
+            nx = rec.e1[1] * rec.e2[2] - rec.e2[1] * rec.e1[2];
+            ny = rec.e1[2] * rec.e2[0] - rec.e2[2] * rec.e1[0];
+            nz = rec.e1[0] * rec.e2[1] - rec.e2[0] * rec.e1[1];
+        }
+        const float inv = 1.0f / sqrtf(dot_zyx(nx, ny, nz, nx, ny, nz));
+        nm = make_float4(nx * inv, ny * inv, nz * inv, __uint_as_float(tri.mat_idx));
+    }
+    position[3 * i] = px; position[3 * i + 1] = py; position[3 * i + 2] = pz;
+    reinterpret_cast<float4 *>(normal_mat)[i] = nm;
 }
 
 // Next frame's schedule (adaptive_order).  Items whose counted cost is at least

@@ -722,20 +722,66 @@ int rtamd_trace(rtamd_context *ctx, uint64_t n, const float *org, const float *d
     return rc;
 }
 
-int rtamd_generate_rays_device(rtamd_context *ctx, uint32_t width, uint32_t height, const float inv_proj_view[16],
-                               float near_plane, float far_plane, float *dir_out) {
+int rtamd_generate_rays_offset_device(rtamd_context *ctx, uint32_t width, uint32_t height, const float inv_proj_view[16],
+                                      float near_plane, float far_plane, float offset_x, float offset_y, float *dir_out) {
     if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
     if (!inv_proj_view || !dir_out || width == 0 || height == 0) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "bad generate_rays arguments");
     if ((uint64_t)width * height > 0x7FFFFFFFull) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "frame too large");
+    if (!(offset_x >= 0.0f && offset_x <= 1.0f && offset_y >= 0.0f && offset_y <= 1.0f)) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "sample offset must lie in [0,1]^2");
     int rc = ensure_ctx_device(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->ipv.p, inv_proj_view, 64, hipMemcpyHostToDevice, ctx->stream));
     uint32_t n = width * height;
-    hipLaunchKernelGGL(k_generate_rays, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const float *)ctx->ipv.p, near_plane, far_plane, width, height, dir_out);
+    hipLaunchKernelGGL(k_generate_rays, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const float *)ctx->ipv.p, near_plane, far_plane, width, height,
+                       offset_x, offset_y, dir_out);
     HIP_TRY(ctx, hipGetLastError());
-    // inv_proj_view is a host pointer that may die after return: make the copy complete
+    // inv_proj_view is a host pointer that may die after return, and ctx->ipv is one staging buffer: make the copy complete
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RTAMD_OK;
+}
+
+int rtamd_generate_rays_device(rtamd_context *ctx, uint32_t width, uint32_t height, const float inv_proj_view[16],
+                               float near_plane, float far_plane, float *dir_out) {
+    return rtamd_generate_rays_offset_device(ctx, width, height, inv_proj_view, near_plane, far_plane, 0.5f, 0.5f, dir_out);
+}
+
+int rtamd_surface_from_hits_device(rtamd_context *ctx, uint64_t n, const float *org, const float *dir, const float *hits, uint32_t has_normals,
+                                   float *position, float *normal_mat) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (!ctx->has_scene) return fail(ctx, RTAMD_ERR_NO_SCENE, "no scene uploaded");
+    if (n == 0) return RTAMD_OK;
+    if (!org || !dir || !hits || !position || !normal_mat) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "surface_from_hits: NULL buffer");
+    if (n > 0xFFFFFFFFull) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "at most 2^32-1 rays per call");
+    if (has_normals && !ctx->normals.p) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "has_normals set but the scene has no normals");
+    if (((uintptr_t)hits | (uintptr_t)normal_mat) & 15u) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "hits / normal_mat must be 16-byte aligned");
+    int rc = ensure_ctx_device(ctx);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_surface_from_hits, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sdev, n, org, dir, hits,
+                       has_normals ? 1u : 0u, position, normal_mat);
+    HIP_TRY(ctx, hipGetLastError());
+    return RTAMD_OK;
+}
+
+int rtamd_surface_from_hits(rtamd_context *ctx, uint64_t n, const float *org, const float *dir, const float *hits, uint32_t has_normals,
+                            float *position, float *normal_mat) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (n == 0) return RTAMD_OK;
+    if (!org || !dir || !hits || !position || !normal_mat) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "surface_from_hits: NULL buffer");
+    int rc = ensure_ctx_device(ctx);
+    if (rc) return rc;
+    DevBuf d_org, d_dir, d_hits, d_pos, d_nm;
+    do {
+        if ((rc = dev_upload(ctx, d_org, org, n * 12)) || (rc = dev_upload(ctx, d_dir, dir, n * 12)) || (rc = dev_upload(ctx, d_hits, hits, n * 16))) break;
+        if ((rc = dev_alloc(ctx, d_pos, n * 12)) || (rc = dev_alloc(ctx, d_nm, n * 16))) break;
+        if ((rc = rtamd_surface_from_hits_device(ctx, n, (const float *)d_org.p, (const float *)d_dir.p, (const float *)d_hits.p, has_normals,
+                                                 (float *)d_pos.p, (float *)d_nm.p))) break;
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipMemcpy(position, d_pos.p, n * 12, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(normal_mat, d_nm.p, n * 16, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = fail(ctx, RTAMD_ERR_DEVICE, "surface_from_hits failed: %s", hipGetErrorString(e)); break; }
+    } while (0);
+    d_org.release(); d_dir.release(); d_hits.release(); d_pos.release(); d_nm.release();
+    return rc;
 }
 
 int rtamd_generate_rays(rtamd_context *ctx, uint32_t width, uint32_t height, const float inv_proj_view[16],

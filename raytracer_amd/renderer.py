@@ -181,6 +181,25 @@ class HipRayTracer:
         self._check(self._lib.rtamd_generate_rays_device(self._h, width, height, inv.ctypes.data_as(_ffi.c_float_p), NEAR, FAR,
                                                          ctypes.c_void_p(dir_ptr)))
 
+    def generate_rays_offset_device(self, width, height, inv_proj_view, offset_x, offset_y, dir_ptr):
+        inv = np.ascontiguousarray(inv_proj_view, dtype=np.float32).reshape(16)
+        self._check(self._lib.rtamd_generate_rays_offset_device(self._h, width, height, inv.ctypes.data_as(_ffi.c_float_p), NEAR, FAR,
+                                                                float(offset_x), float(offset_y), ctypes.c_void_p(dir_ptr)))
+
+    # ---- hit records -> G-buffer ---------------------------------------------
+    def surface_from_hits(self, org, dir, hits, has_normals=False):
+        o = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dir, dtype=np.float32).reshape(-1, 3)
+        h = np.ascontiguousarray(hits, dtype=np.float32).reshape(-1, 4)
+        pos = np.zeros((len(h), 3), np.float32)
+        nm = np.zeros((len(h), 4), np.float32)
+        self._check(self._lib.rtamd_surface_from_hits(self._h, len(h), _ptr(o), _ptr(d), _ptr(h), int(bool(has_normals)), _ptr(pos), _ptr(nm)))
+        return pos, nm
+
+    def surface_from_hits_device(self, n, org_ptr, dir_ptr, hits_ptr, has_normals, position_ptr, normal_mat_ptr):
+        self._check(self._lib.rtamd_surface_from_hits_device(self._h, int(n), ctypes.c_void_p(org_ptr), ctypes.c_void_p(dir_ptr), ctypes.c_void_p(hits_ptr),
+                                                             int(bool(has_normals)), ctypes.c_void_p(position_ptr), ctypes.c_void_p(normal_mat_ptr)))
+
     # ---- secondary rays (ray_dispatcher.frag) -------------------------------
     def upload_noise_texture(self, rgb8):
         t = np.ascontiguousarray(rgb8, dtype=np.uint8)

@@ -85,7 +85,21 @@ class OracleA:
         L.oa_set_flush_denormals.argtypes = [ctypes.c_int]
         L.oa_dispatch.argtypes = [ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp]
         L.oa_dispatch.restype = None
+        L.oa_surface_from_hits.argtypes = [ctypes.POINTER(_Scene), ctypes.c_uint64, vp, vp, vp, ctypes.c_int, vp, vp]
+        L.oa_surface_from_hits.restype = None
         self.L = L
+
+    def surface_from_hits(self, scene, org, dir, hits, has_normals):
+        keep = []
+        sc = _scene_struct(scene, keep)
+        o = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dir, dtype=np.float32).reshape(-1, 3)
+        h = np.ascontiguousarray(hits, dtype=np.float32).reshape(-1, 4)
+        n = len(h)
+        pos = np.zeros((n, 3), np.float32)
+        nm = np.zeros((n, 4), np.float32)
+        self.L.oa_surface_from_hits(ctypes.byref(sc), n, o.ctypes.data, d.ctypes.data, h.ctypes.data, int(has_normals), pos.ctypes.data, nm.ctypes.data)
+        return pos, nm
 
     def dispatch(self, position, normal_mat, noise_rgb, light_pos, camera_pos, noise_offset_scale):
         """ray_dispatcher.frag over an (h, w) G-buffer (row 0 = bottom) -> dict(org, shadow_dir, reflect_dir, ambient_dir)."""

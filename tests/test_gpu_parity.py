@@ -128,3 +128,63 @@ def test_ray_dispatcher_device_entry_and_trace_pipeline(tracer, oracle_a):
         assert np.array_equal(bits(got), bits(want)), k
         assert np.all(got[~surface, 0] == np.float32(1e30)) and np.all(got[~surface, 1:] == 0)
     assert (hits["shadow_dir"].cpu().numpy()[surface, 0] < 1e30).sum() > 100   # some surface points are shadowed
+
+
+@pytest.mark.parametrize("name", ["bunny", "teapot", "f16"])
+def test_surface_from_hits_and_two_bounces_match_oracle(tracer, oracle_a, name):
+    """Hit records -> G-buffer (interpolated normals for bunny / f16, flat for teapot) and the repeated
+    dispatcher -> trace loop the reference's one-bounce pipeline stops short of: every buffer of two bounces
+    (surface, four ray targets, three hit-record sets per bounce) equals oracle A bit for bit."""
+    g = load_golden(name)
+    d = load_golden("dispatch")
+    tracer.upload_scene(g["scene"])
+    tracer.upload_noise_texture(d["noise"])
+    has_n = int(g["has_normals"])
+    h, w = g["dir"].shape[:2]
+    org, dirs = g["org"].reshape(-1, 3), g["dir"].reshape(-1, 3)
+    hits = tracer.trace(org, dirs)
+    assert np.array_equal(bits(hits), bits(g["b_trace"].reshape(-1, 4)))
+    light, nos = d["light_pos"], d["noise_offset_scale"]
+    cam = org[0]
+    for bounce in range(2):
+        pos, nm = tracer.surface_from_hits(org, dirs, hits, has_n)
+        apos, anm = oracle_a.surface_from_hits(g["scene"], org, dirs, hits, has_n)
+        assert np.array_equal(bits(pos), bits(apos)) and np.array_equal(bits(nm), bits(anm)), bounce
+        surface = nm[:, 3] != np.float32(1e30)
+        assert np.array_equal(surface, hits[:, 0] < np.float32(1e30)) and surface.sum() > (1000 if bounce == 0 else 10)
+        r = tracer.dispatch_rays(pos.reshape(h, w, 3), nm.reshape(h, w, 4), light, cam, nos)
+        a = oracle_a.dispatch(pos.reshape(h, w, 3), nm.reshape(h, w, 4), d["noise"], light, cam, nos)
+        for k in DISPATCH_KEYS:
+            assert np.array_equal(bits(r[k]), bits(a[k])), (bounce, k)
+        org = r["org"].reshape(-1, 3)
+        for k in DISPATCH_KEYS[1:]:
+            got = tracer.trace(org, r[k].reshape(-1, 3))
+            want = oracle_a.trace(g["scene"], org, r[k].reshape(-1, 3))["hits"]
+            assert np.array_equal(bits(got), bits(want)), (bounce, k)
+            if k == "reflect_dir":
+                next_hits, next_dirs = got, r[k].reshape(-1, 3)
+        hits, dirs = next_hits, next_dirs
+
+
+def test_offset_ray_generation(tracer, oracle_a):
+    """Sample offset (0.5, 0.5) is the pixel-centre generator bit for bit; other offsets move every ray
+    continuously between its neighbours' directions."""
+    import torch
+    g = load_golden("bunny")
+    tracer.upload_scene(g["scene"])
+    cam = __import__("raytracer_amd").host.Camera(4 / 3, position=(0.5, 0.2, 2.0), direction=(0.0, 0.0, -1.0))
+    inv = cam.inv_proj_view()
+    W, H = 64, 48
+    dev = torch.device("cuda", 0)
+    out = [torch.zeros((W * H, 3), dtype=torch.float32, device=dev) for _ in range(3)]
+    tracer.generate_rays_device(W, H, inv, out[0].data_ptr())
+    tracer.generate_rays_offset_device(W, H, inv, 0.5, 0.5, out[1].data_ptr())
+    tracer.generate_rays_offset_device(W, H, inv, 1.0, 0.5, out[2].data_ptr())
+    tracer.synchronize()
+    c, same, right = (o.cpu().numpy().reshape(H, W, 3) for o in out)
+    assert np.array_equal(bits(c), bits(same))
+    mid = (c[:, :-1] + c[:, 1:]) / 2
+    mid /= np.linalg.norm(mid, axis=-1, keepdims=True)
+    assert np.abs(right[:, :-1] - mid).max() < 2e-3
+    with pytest.raises(Exception):
+        tracer.generate_rays_offset_device(W, H, inv, 1.5, 0.5, out[2].data_ptr())
