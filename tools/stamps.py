@@ -17,7 +17,7 @@ d_org = torch.tensor(np.asarray(camera.position, np.float32), device=dev).repeat
 d_rgba = torch.zeros((n, 4), dtype=torch.float32, device=dev)
 tr.set_option('leaf_thresh', 8)
 prev_dur = prev_ok = None
-for th, nq, ad, pr in ((1, 8, 0, 0), (1, 8, 1, 0)):
+for th, nq, ad, pr in ((1, 8, 0, 0),):
     tr.set_option('heavy_factor_x4', 8)
     tr.set_option('adaptive_order', ad); tr.set_option('prio_thresh', pr); print(f'--- prio_thresh {pr}')
     tr.set_option("dyn_thresh", th); tr.set_option("num_queues", nq)
