@@ -188,3 +188,31 @@ def test_offset_ray_generation(tracer, oracle_a):
     assert np.abs(right[:, :-1] - mid).max() < 2e-3
     with pytest.raises(Exception):
         tracer.generate_rays_offset_device(W, H, inv, 1.5, 0.5, out[2].data_ptr())
+
+
+@pytest.mark.parametrize("w,h", [(37, 19), (1, 1), (8, 65), (131, 3)])
+def test_ragged_frame_sizes_and_ray_counts(tracer, oracle_a, w, h):
+    """Frames that are not multiples of the 8x8 work item / 32x32 tile, and ray counts that are not
+    multiples of 64: every pixel / ray equals oracle A, nothing outside the frame is written."""
+    g = load_golden("f16")
+    _upload(tracer, g)
+    dirs = np.ascontiguousarray(g["dir"][40:40 + h, 60:60 + w]) if h <= 80 and w <= 100 else np.ascontiguousarray(g["dir"].reshape(-1, 3)[:w * h].reshape(h, w, 3))
+    orgs = np.broadcast_to(g["org"][0, 0], dirs.shape).copy()
+    for variant in (0, 1):
+        tracer.set_kernel_variant(variant)
+        try:
+            r = tracer.render(w, h, dir=dirs, org=orgs, has_tex_coords=1, has_normals=1, want=("rgba", "hit_id", "hit_t"))
+            t = tracer.trace(orgs.reshape(-1, 3), dirs.reshape(-1, 3))
+        finally:
+            tracer.set_kernel_variant(0)
+        a = oracle_a.render(g["scene"], dirs, orgs, 1, 1, g["tex0"], g["tex1"])
+        assert r["rgba"].shape == (w * h, 4)
+        assert np.array_equal(r["hit_id"], a["hit_id"]) and np.array_equal(bits(r["hit_t"]), bits(a["hit_t"]))
+        assert rgb_err_255(a["rgba"], r["rgba"]).max() <= 0.05
+        assert np.array_equal(bits(t), bits(oracle_a.trace(g["scene"], orgs, dirs)["hits"]))
+    # tile shards of a ragged frame: 3 ranks, compact tile buffers re-assemble to the frame
+    from raytracer_amd.renderer import assemble_tiles_host
+    parts = [tracer.render(w, h, dir=dirs, org=orgs, has_tex_coords=1, has_normals=1, tile_rank=k, tile_world=3)["rgba"] for k in range(3)]
+    per = tracer.tiles_per_rank(w, h, 3) * 1024
+    frame = assemble_tiles_host([np.concatenate([p, np.zeros((per - len(p), 4), np.float32)]) for p in parts], w, h, 3, 4).reshape(-1, 4)
+    assert np.array_equal(bits(frame), bits(r["rgba"]))
