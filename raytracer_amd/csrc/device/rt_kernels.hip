@@ -89,6 +89,7 @@ struct JobParams {
     uint32_t leaf_thresh;
     uint32_t shadow_anyhit;       // fused mode: shadow rays stop at the first leaf that leaves t < T_HIT_LIMIT
     uint32_t queue_stride;        // u32 words between queue counters
+    uint32_t queue_block;         // consecutive schedule positions a queue owns per turn
     uint32_t chunk;               // schedule positions taken per atomic
     uint32_t prio_thresh;         // 0 = off; else a wave raises its issue priority when its item has cost this much work (x2, x4)
     const uint32_t *item_order;   // schedule position -> item, or nullptr (identity)
@@ -535,7 +536,10 @@ __device__ __forceinline__ uint32_t fetch_item(const JobParams &p, uint32_t home
         if (q.v_next < q.v_end) {
             // queue k serves schedule positions k, k + nq, k + 2nq, ...: every queue sees the
             // same profile of the schedule
-            const uint32_t pos = q.v_next * p.n_queues + q.k;
+            // with queue_block B > 1 a queue owns runs of B consecutive positions (B items = a compact
+            // screen region) instead of single positions: the waves of one XCD then share more of their nodes
+            const uint32_t pos = p.queue_block == 1u ? q.v_next * p.n_queues + q.k
+                                                     : ((q.v_next / p.queue_block) * p.n_queues + q.k) * p.queue_block + q.v_next % p.queue_block;
             q.v_next++;
             if (pos < p.n_items) return p.item_order ? p.item_order[pos] : pos;
             q.v_next = q.v_end;   // this queue is exhausted

@@ -80,6 +80,7 @@ struct rtamd_context {
     bool shadow_anyhit = true;
     uint32_t heavy_num = 8;   // adaptive_order: items costing >= heavy_num/4 x mean go first
     uint32_t queue_stride = 64, chunk = 1;
+    uint32_t queue_block_fused = 256, queue_block_trace = 1;   // measured: 256-item regions per XCD turn help camera frames 1.5 %, not ray lists
     uint32_t n_queues = 8;
 };
 
@@ -187,7 +188,7 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     p.leaf_thresh = ctx->leaf_thresh;
     p.prio_thresh = ctx->prio_thresh;
     p.shadow_anyhit = ctx->shadow_anyhit ? 1u : 0u;
-    p.queue_stride = ctx->queue_stride; p.chunk = ctx->chunk;
+    p.queue_stride = ctx->queue_stride; p.chunk = ctx->chunk; p.queue_block = mode == MODE_FUSED ? ctx->queue_block_fused : ctx->queue_block_trace;
     p.spill = (uint32_t *)sl->spill.p;
     p.item_cost = nullptr; p.item_order = nullptr;
     if (ctx->variant == 0 && ctx->adaptive_order) {
@@ -387,6 +388,9 @@ int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value) {
     } else if (!std::strcmp(name, "queue_stride")) {
         if (value < 1 || value > 4096) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "queue_stride must be 1..4096 words");
         ctx->queue_stride = (uint32_t)value;
+    } else if (!std::strcmp(name, "queue_block")) {
+        if (value < 1 || value > 65536) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "queue_block must be 1..65536");
+        ctx->queue_block_fused = ctx->queue_block_trace = (uint32_t)value;
     } else if (!std::strcmp(name, "chunk")) {
         if (value < 1 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "chunk must be 1..64");
         ctx->chunk = (uint32_t)value;
