@@ -43,6 +43,9 @@ struct rtamd_context {
         hipEvent_t ev_start = nullptr, ev_stop = nullptr;
         bool ev_valid = false;
         DevBuf queues, spill;
+        uint64_t launches = 0;              // persistent-kernel launches on this stream since the statistics layout last changed
+        int stats_mode = -1;                // mode of the launch that wrote the latest statistics
+        uint32_t *stats_last = nullptr;     // where that launch put them
         // adaptive_order: per-item cost counted by launch f orders the items of launch f+1
         DevBuf item_cost, item_order;
         uint32_t order_items[2] = {0, 0};   // n_items the schedule of mode [fused, trace] is valid for (0 = none yet)
@@ -74,7 +77,9 @@ struct rtamd_context {
     // measured defaults (tools/kbench.py): coherent camera/shadow rays run best without lane
     // re-fill (1), incoherent ray streams with re-fill below 32 busy lanes; leaves are
     // released when 8 lanes wait
-    uint32_t dyn_thresh_fused = 1, dyn_thresh_trace = 32;
+    uint32_t dyn_thresh_fused = 1, dyn_thresh_trace = 32;   // starting values; with dyn_auto the kernel adapts them per launch
+    bool dyn_auto = true;
+    uint32_t dyn_incoherent = 32;
     uint32_t leaf_thresh = 8;
     uint32_t prio_thresh = 0;
     bool shadow_anyhit = true;
@@ -148,7 +153,8 @@ int ensure_ctx_device(rtamd_context *ctx) {
     return RTAMD_OK;
 }
 
-constexpr size_t QUEUE_BYTES = 32 * 16384;   // num_queues <= 32, queue_stride <= 4096 words
+constexpr size_t QUEUE_HEADROOM_WORDS = 64;   // room for the odd launches' statistics pair in front of the counters
+constexpr size_t QUEUE_BYTES = 256 + 32 * 16384 + 256;   // headroom + (num_queues <= 32) * (queue_stride <= 4096 words) + the even pair
 
 // The scratch slot of the context's current stream (created on first use).
 int acquire_slot(rtamd_context *ctx, rtamd_context::Slot **out) {
@@ -168,6 +174,7 @@ int acquire_slot(rtamd_context *ctx, rtamd_context::Slot **out) {
         HIP_TRY(ctx, hipMemset(sl->queues.p, 0, QUEUE_BYTES));
     }
     if (!sl->spill.p && (rc = dev_alloc(ctx, sl->spill, ctx->spill_bytes))) return rc;
+    sl->launches = 0; sl->stats_last = nullptr;
     sl->key = ctx->stream; sl->bound = true; sl->ev_valid = false;
     sl->order_items[0] = sl->order_items[1] = 0;
     sl->last_use = ++ctx->use_clock;
@@ -182,9 +189,12 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     int rc_slot = acquire_slot(ctx, &sl);
     if (rc_slot) return rc_slot;
     ctx->last_slot = (int)(sl - ctx->slots);
-    p.queues = (uint32_t *)sl->queues.p;
+    p.queues = (uint32_t *)sl->queues.p + QUEUE_HEADROOM_WORDS;
     p.n_queues = ctx->n_queues;
     p.dyn_thresh = mode == MODE_FUSED ? ctx->dyn_thresh_fused : ctx->dyn_thresh_trace;
+    p.dyn_auto = ctx->dyn_auto ? 1u : 0u;
+    p.dyn_incoherent = ctx->dyn_incoherent;
+    p.stats_prev = nullptr; p.stats_cur = nullptr;
     p.leaf_thresh = ctx->leaf_thresh;
     p.prio_thresh = ctx->prio_thresh;
     p.shadow_anyhit = ctx->shadow_anyhit ? 1u : 0u;
@@ -211,7 +221,22 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     const SceneDev &s = ctx->sdev;
     // (Letting the last wave of a launch zero the counters instead — one exit atomic per wave — was measured
     // equal for the fused shader and 5 % slower for ray_trace launches, whose waves all leave at once.)
-    if (ctx->variant == 0) HIP_TRY(ctx, hipMemsetAsync(sl->queues.p, 0, (size_t)ctx->n_queues * ctx->queue_stride * sizeof(uint32_t), st));
+    if (ctx->variant == 0) {
+        // One memset per launch zeroes the queue counters and this launch's statistics pair; the pair
+        // the previous launch wrote sits on the other side of the counters and survives:
+        //   [ stats of odd launches | queue counters (n_queues * stride words) | stats of even launches ]
+        uint32_t *q = (uint32_t *)sl->queues.p + QUEUE_HEADROOM_WORDS;
+        const size_t q_words = (size_t)ctx->n_queues * ctx->queue_stride;
+        uint32_t *stats_odd = q - 2, *stats_even = q + q_words;
+        const bool odd = (sl->launches & 1u) != 0;
+        p.queues = q;
+        p.stats_cur = odd ? stats_odd : stats_even;
+        if (sl->launches > 0 && sl->stats_mode == mode) p.stats_prev = odd ? stats_even : stats_odd;   // the previous launch here was of this kind
+        sl->launches++;
+        sl->stats_mode = mode;
+        sl->stats_last = p.stats_cur;
+        HIP_TRY(ctx, hipMemsetAsync(odd ? (void *)stats_odd : (void *)q, 0, (q_words + 2) * sizeof(uint32_t), st));
+    }
     HIP_TRY(ctx, hipEventRecord(sl->ev_start, st));
     if (ctx->variant == 0) {
         int per_cu = ctx->persistent_blocks_per_cu[mode * 2 + (count ? 1 : 0)];
@@ -377,8 +402,10 @@ int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value) {
     if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
     if (!name) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "option name is NULL");
     if (!std::strcmp(name, "dyn_thresh")) {
-        if (value < 1 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "dyn_thresh must be 1..64");
-        ctx->dyn_thresh_fused = ctx->dyn_thresh_trace = (uint32_t)value;
+        if (value < 0 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "dyn_thresh must be 0 (auto) or 1..64");
+        if (value == 0) { ctx->dyn_auto = true; ctx->dyn_thresh_fused = 1; ctx->dyn_thresh_trace = 32; }
+        else { ctx->dyn_auto = false; ctx->dyn_thresh_fused = ctx->dyn_thresh_trace = (uint32_t)value; }
+        for (auto &sl : ctx->slots) sl.launches = 0;
     } else if (!std::strcmp(name, "leaf_thresh")) {
         if (value < 1 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "leaf_thresh must be 1..64");
         ctx->leaf_thresh = (uint32_t)value;
@@ -388,6 +415,7 @@ int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value) {
     } else if (!std::strcmp(name, "queue_stride")) {
         if (value < 1 || value > 4096) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "queue_stride must be 1..4096 words");
         ctx->queue_stride = (uint32_t)value;
+        for (auto &sl : ctx->slots) sl.launches = 0;
     } else if (!std::strcmp(name, "queue_block")) {
         if (value < 1 || value > 65536) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "queue_block must be 1..65536");
         ctx->queue_block_fused = ctx->queue_block_trace = (uint32_t)value;
@@ -405,6 +433,7 @@ int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value) {
     } else if (!std::strcmp(name, "num_queues")) {
         if (value < 1 || value > 32) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "num_queues must be 1..32");
         ctx->n_queues = (uint32_t)value;
+        for (auto &sl : ctx->slots) sl.launches = 0;
     } else if (!std::strcmp(name, "kernel_variant")) {
         return rtamd_set_kernel_variant(ctx, (int)value);
     } else {
@@ -852,6 +881,18 @@ int rtamd_exp_read_stamps(rtamd_context *ctx, unsigned long long *out, uint32_t 
     return RTAMD_OK;
 }
 #endif
+
+int rtamd_last_launch_coherence(rtamd_context *ctx, float *uniform_fraction) {
+    if (!ctx || !uniform_fraction) return RTAMD_ERR_INVALID_ARGUMENT;
+    const rtamd_context::Slot *sl = nullptr;
+    for (const auto &c : ctx->slots) if (c.bound && c.key == ctx->stream && c.ev_valid && c.stats_last) sl = &c;
+    if (!sl) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "no persistent-kernel launch on the current stream yet");
+    HIP_TRY(ctx, hipEventSynchronize(sl->ev_stop));
+    uint32_t v[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpy(v, sl->stats_last, sizeof v, hipMemcpyDeviceToHost));
+    *uniform_fraction = v[1] ? (float)v[0] / (float)v[1] : 0.0f;
+    return RTAMD_OK;
+}
 
 int rtamd_last_kernel_ms(rtamd_context *ctx, float *ms) {
     if (!ctx || !ms) return RTAMD_ERR_INVALID_ARGUMENT;

@@ -68,6 +68,11 @@ class HipRayTracer:
         self._check(self._lib.rtamd_last_kernel_ms(self._h, ctypes.byref(ms)))
         return ms.value
 
+    def last_launch_coherence(self):
+        v = ctypes.c_float()
+        self._check(self._lib.rtamd_last_launch_coherence(self._h, ctypes.byref(v)))
+        return v.value
+
     def scene_info(self):
         info = _ffi.SceneInfo()
         self._check(self._lib.rtamd_get_scene_info(self._h, ctypes.byref(info)))

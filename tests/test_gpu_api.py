@@ -144,7 +144,7 @@ def test_full_size_atrium_properties(tracer, oracle_a, atrium):
     tracer.upload_texture(0, tex[0]); tracer.upload_texture(1, tex[1])
     inv = camera.inv_proj_view()
     ref = None
-    defaults = {"kernel_variant": 0, "dyn_thresh": 1, "leaf_thresh": 8, "num_queues": 8, "queue_stride": 64, "chunk": 1,
+    defaults = {"kernel_variant": 0, "dyn_thresh": 0, "leaf_thresh": 8, "num_queues": 8, "queue_stride": 64, "chunk": 1,
                 "prio_thresh": 0, "adaptive_order": 0, "shadow_anyhit": 1, "queue_block": 256}
     try:
         tracer.set_option("shadow_anyhit", 0)   # reference-length shadow traversals: counters comparable with the oracle
@@ -154,7 +154,7 @@ def test_full_size_atrium_properties(tracer, oracle_a, atrium):
                      {"kernel_variant": 0, "dyn_thresh": 40, "leaf_thresh": 64, "num_queues": 1, "queue_stride": 16, "chunk": 3},
                      {"kernel_variant": 0, "dyn_thresh": 64, "leaf_thresh": 1, "num_queues": 3, "prio_thresh": 50, "queue_block": 7},
                      {"kernel_variant": 0, "dyn_thresh": 1, "leaf_thresh": 8, "num_queues": 16, "adaptive_order": 1, "chunk": 1, "prio_thresh": 0},
-                     {"kernel_variant": 0, "adaptive_order": 1}):
+                     {"kernel_variant": 0, "adaptive_order": 1}, {"kernel_variant": 0, "dyn_thresh": 0}, {"kernel_variant": 0, "dyn_thresh": 0}):
             for k, v in opts.items():
                 tracer.set_option(k, v)
             r = tracer.render(W, H, camera=(inv, camera.position), has_tex_coords=1, has_normals=1, want=("rgba", "hit_id", "hit_t", "counts"))
@@ -304,3 +304,26 @@ def test_full_size_soup_10m_4k(tracer, oracle_a):
     a = oracle_a.render(sc, dirs.reshape(-1, 3)[sel], orgs.reshape(-1, 3)[sel], 0, 0, nthreads=16)
     assert np.array_equal(a["hit_id"], full["hit_id"][sel]) and np.array_equal(bits(a["hit_t"]), bits(full["hit_t"][sel]))
     assert rgb_err_255(a["rgba"], full["rgba"][sel]).max() <= 0.05
+
+
+def test_coherence_feedback_separates_camera_rays_from_soup(tracer, atrium):
+    """dyn_thresh = auto steers by the share of wave-uniform node visits of the previous launch: camera frames of
+    the atrium sit well above the 0.3 switch point, a triangle soup and shuffled rays well below; whatever the
+    threshold in force, outputs do not change."""
+    sc, camera, tex = atrium
+    W, H = 640, 360
+    inv = camera.inv_proj_view()
+    tracer.set_option("dyn_thresh", 0)
+    tracer.upload_scene(sc)
+    tracer.upload_texture(0, tex[0]); tracer.upload_texture(1, tex[1])
+    frames = [tracer.render(W, H, camera=(inv, camera.position), has_tex_coords=1, has_normals=1)["rgba"] for _ in range(3)]
+    assert tracer.last_launch_coherence() > 0.4
+    assert all(np.array_equal(bits(frames[0]), bits(f)) for f in frames[1:])
+    tri, pos, cam = scenes.triangle_soup(100_000, seed=5, extent=30.0)
+    m = host.Model.from_arrays(tri, pos)
+    m.build_bvh(4)
+    tracer.upload_scene(m.scene_arrays())
+    c2 = host.Camera(W / H, fov=math.radians(60), position=(0.0, 0.0, -75.0), direction=(0.0, 0.0, 1.0))
+    frames = [tracer.render(W, H, camera=(c2.inv_proj_view(), c2.position))["rgba"] for _ in range(3)]
+    assert tracer.last_launch_coherence() < 0.3
+    assert all(np.array_equal(bits(frames[0]), bits(f)) for f in frames[1:])

@@ -49,6 +49,7 @@ def main():
         opts = dict(x.split("=") for x in kv.split(",")) if kv else {}
         arms.append((name, opts))
     res = {name: [] for name, _ in arms}
+    coh = {}
     import time
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.inflight))]
     outs = [torch.zeros((n, 4), dtype=torch.float32, device=dev) for _ in streams]
@@ -57,7 +58,7 @@ def main():
         for name, o in arms:
             tr.set_option("kernel_variant", int(o.get("variant", 0)))
             mode = o.get("mode", "fused")
-            tr.set_option("dyn_thresh", int(o.get("dyn_thresh", 1 if mode == "fused" else 32)))
+            tr.set_option("dyn_thresh", int(o.get("dyn_thresh", 0)))
             tr.set_option("num_queues", int(o.get("num_queues", 8)))
             tr.set_option("leaf_thresh", int(o.get("leaf_thresh", 8)))
             tr.set_option("prio_thresh", int(o.get("prio_thresh", 0)))
@@ -81,6 +82,7 @@ def main():
                     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 24 * 1e3
                 if r >= 2:
                     res[name].append(dt)
+                coh[name] = tr.last_launch_coherence() if int(o.get("variant", 0)) == 0 else -1.0
                 continue
             for _ in range(3):   # the schedule of a launch comes from the previous launch of the same arm
                 if mode == "fused":
@@ -95,7 +97,7 @@ def main():
     lib = os.environ.get("RTAMD_DEVICE_LIB", "default")
     for name, _ in arms:
         v = np.array(res[name])
-        print(json.dumps({"lib": os.path.basename(lib), "arm": name, "median_ms": round(float(np.median(v)), 4), "min_ms": round(float(v.min()), 4)}))
+        print(json.dumps({"lib": os.path.basename(lib), "arm": name, "median_ms": round(float(np.median(v)), 4), "min_ms": round(float(v.min()), 4), "coherence": round(coh.get(name, -1.0), 3)}))
 
 
 if __name__ == "__main__":

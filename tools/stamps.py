@@ -7,10 +7,11 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import torch, bench
 from raytracer_amd.renderer import HipRayTracer
-model, camera, W, H, tex = bench.build_workload("atrium_1080p")
+model, camera, W, H, tex = bench.build_workload(sys.argv[1] if len(sys.argv) > 1 else "atrium_1080p")
 sc = model.scene_arrays(); dev = torch.device("cuda", 0)
 tr = HipRayTracer(0); tr.upload_scene(sc)
-for slot, t in enumerate(tex): tr.upload_texture(slot, t)
+for slot, t in enumerate(tex):
+    if t is not None: tr.upload_texture(slot, t)
 n = W * H
 d_dir = torch.empty((n, 3), dtype=torch.float32, device=dev); tr.generate_rays_device(W, H, camera.inv_proj_view(), d_dir.data_ptr())
 d_org = torch.tensor(np.asarray(camera.position, np.float32), device=dev).repeat(n, 1).contiguous()
@@ -22,7 +23,7 @@ for th, nq, ad, pr in ((1, 8, 0, 0),):
     tr.set_option('adaptive_order', ad); tr.set_option('prio_thresh', pr); print(f'--- prio_thresh {pr}')
     tr.set_option("dyn_thresh", th); tr.set_option("num_queues", nq)
     for _ in range(3):
-        tr.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=True, has_normals=True, rgba_ptr=d_rgba.data_ptr())
+        tr.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=model.has_tex_coords(), has_normals=model.has_normals(), rgba_ptr=d_rgba.data_ptr())
     ms = tr.last_kernel_ms()
     waves = 8192
     buf = np.zeros((waves, 16), np.uint64)
