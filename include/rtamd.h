@@ -276,6 +276,8 @@ int rtamd_set_kernel_variant(rtamd_context *ctx, int variant);
  *  "queue_stride" 1..4096  u32 words between the counters (default 64 = 256 B, one memory
  *                       channel each);
  *  "chunk" 1..64        schedule positions a wave takes per atomic (default 1);
+ *  "max_blocks_per_cu" 0..64  cap on resident workgroups per CU (0 = all that fit, 8); 6 is 2.5-4 % faster on
+ *                       incoherent rays, 8 on coherent ones;
  *  "queue_block" 1..65536  consecutive schedule positions (work items) a queue owns per turn, i.e. the size of
  *                       the screen region the waves of one XCD share (default 256 for frames, 1 for ray lists);
  *  "prio_thresh" >= 0   0 = off (default); else a wave raises its issue priority once its

@@ -85,6 +85,7 @@ struct rtamd_context {
     bool shadow_anyhit = true;
     uint32_t heavy_num = 8;   // adaptive_order: items costing >= heavy_num/4 x mean go first
     uint32_t queue_stride = 64, chunk = 1;
+    uint32_t max_blocks_per_cu = 0;   // 0 = as many as fit (8 workgroups = 8 waves per SIMD)
     uint32_t queue_block_fused = 256, queue_block_trace = 1;   // measured: 256-item regions per XCD turn help camera frames 1.5 %, not ray lists
     uint32_t n_queues = 8;
 };
@@ -240,6 +241,7 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     HIP_TRY(ctx, hipEventRecord(sl->ev_start, st));
     if (ctx->variant == 0) {
         int per_cu = ctx->persistent_blocks_per_cu[mode * 2 + (count ? 1 : 0)];
+        if (ctx->max_blocks_per_cu && (int)ctx->max_blocks_per_cu < per_cu) per_cu = (int)ctx->max_blocks_per_cu;
         uint32_t grid = (uint32_t)(ctx->num_cu * per_cu);
         uint32_t need = (p.n_items + (BLOCK / 64) - 1) / (BLOCK / 64);
         if (grid > need) grid = need;
@@ -419,6 +421,9 @@ int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value) {
     } else if (!std::strcmp(name, "queue_block")) {
         if (value < 1 || value > 65536) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "queue_block must be 1..65536");
         ctx->queue_block_fused = ctx->queue_block_trace = (uint32_t)value;
+    } else if (!std::strcmp(name, "max_blocks_per_cu")) {
+        if (value < 0 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "max_blocks_per_cu must be 0..64");
+        ctx->max_blocks_per_cu = (uint32_t)value;
     } else if (!std::strcmp(name, "chunk")) {
         if (value < 1 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "chunk must be 1..64");
         ctx->chunk = (uint32_t)value;

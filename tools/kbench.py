@@ -64,6 +64,7 @@ def main():
             tr.set_option("prio_thresh", int(o.get("prio_thresh", 0)))
             tr.set_option("queue_stride", int(o.get("queue_stride", 64)))
             tr.set_option("chunk", int(o.get("chunk", 1)))
+            tr.set_option("max_blocks_per_cu", int(o.get("blocks", 0)))
             tr.set_option("queue_block", int(o.get("queue_block", 256 if o.get("mode", "fused") == "fused" else 1)))
             tr.set_option("heavy_factor_x4", int(o.get("heavy", 8)))
             tr.set_option("shadow_anyhit", int(o.get("anyhit", 1)))
