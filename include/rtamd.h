@@ -254,10 +254,11 @@ int rtamd_get_scene_info(const rtamd_context *ctx, rtamd_scene_info *info);
  * with HIP events on the stream it ran on (blocks until that kernel is done). */
 int rtamd_last_kernel_ms(rtamd_context *ctx, float *ms);
 
-/* Share of the node visits of the last render / trace launch on the current stream in which every active lane
- * of a wave visited the same node (sampled over 1/8 of the waves; blocks until that launch is done).  It is the
- * signal "dyn_thresh" = auto steers by: camera and sun-shadow rays measure about 0.5, triangle soups under 0.1. */
-int rtamd_last_launch_coherence(rtamd_context *ctx, float *uniform_fraction);
+/* What the last render / trace launch on the current stream measured about its rays (sampled over 1/8 of the
+ * waves; blocks until that launch is done; any output may be NULL): the share of node visits in which every
+ * active lane of a wave visited the same node, the share of lanes active per visit, and the lane re-fill
+ * threshold the launch ran with.  These are the signals "dyn_thresh" = auto steers by. */
+int rtamd_last_launch_coherence(rtamd_context *ctx, float *uniform_fraction, float *lane_utilisation, uint32_t *dyn_thresh_used);
 
 /* Kernel variant used by render/trace: 0 = default (persistent wave64 queue),
  * 1 = one lane per pixel, static 8x8 blocks (A/B baseline). */
@@ -267,9 +268,10 @@ int rtamd_set_kernel_variant(rtamd_context *ctx, int variant);
  * change):
  *  "dyn_thresh" 0..64   re-fill idle lanes from the next work item when fewer than this many lanes of a
  *                       wave are still traversing (1 = only when the whole wave is done).  0 = auto (default):
- *                       each launch reads the share of wave-uniform node visits the previous launch of the
- *                       same kind on the same stream measured and uses 1 for coherent rays (camera, sun shadow)
- *                       and 32 for incoherent ones (soups, bounces); the first launch uses 1 (render) / 32 (trace);
+ *                       each launch reads what the previous launch of the same kind on the same stream
+ *                       measured and keeps 1 while at least 50 % of the lanes are active per node visit
+ *                       (camera rays, sun shadow rays), switches to 32 below that (triangle soups, bounces)
+ *                       for 64 launches, then probes one launch at 1 again; the first launch uses 1;
  *  "leaf_thresh" 1..64  lanes waiting at a leaf are served once this many wait (64 = classic
  *                       while-while traversal, 1 = if-if);
  *  "num_queues" 1..32   work-queue counters (8 = one per XCD);

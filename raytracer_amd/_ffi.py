@@ -173,7 +173,7 @@ def device_lib():
         L.rtamd_generate_rays_offset_device.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, c_float_p, ctypes.c_float, ctypes.c_float,
                                                         ctypes.c_float, ctypes.c_float, vp]
         L.rtamd_generate_rays_offset_device.restype = ctypes.c_int
-        L.rtamd_last_launch_coherence.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+        L.rtamd_last_launch_coherence.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint32)]
         L.rtamd_last_launch_coherence.restype = ctypes.c_int
         L.rtamd_upload_noise_texture.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint32]
         L.rtamd_upload_noise_texture.restype = ctypes.c_int

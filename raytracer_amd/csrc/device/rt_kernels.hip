@@ -89,7 +89,7 @@ struct JobParams {
     uint32_t leaf_thresh;
     uint32_t shadow_anyhit;       // fused mode: shadow rays stop at the first leaf that leaves t < T_HIT_LIMIT
     uint32_t queue_stride;        // u32 words between queue counters
-    // coherence feedback (dyn_thresh auto): {wave-uniform visits, visits} summed over a sample of the waves;
+    // coherence feedback (dyn_thresh auto): {wave-uniform visits, visits, active lanes, threshold used} over a sample of the waves;
     // stats_prev = what the previous launch of this mode on this stream measured (nullptr: none yet)
     const uint32_t *stats_prev;
     uint32_t *stats_cur;
@@ -602,15 +602,23 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
     unsigned long long snap_inner = 0, snap_leaf = 0, snap_uniform = 0, snap_lanes = 0, w_inner = 0, w_leaf = 0, w_uniform = 0, w_lanes = 0;
 #endif
 
-    // Lane re-fill threshold.  Rays that walk the tree together (camera rays, sun shadow rays: more than
-    // 30 % of the visits wave-uniform) run best when an item is finished before the next is started (1);
-    // incoherent rays (triangle soup, bounces) gain 6-25 % from re-filling idle lanes below 32 busy ones.
-    uint32_t dyn_thresh = p.dyn_thresh;
+    // Lane re-fill threshold, chosen from what the previous launch of this kind on this stream measured
+    // (stats: {wave-uniform visits, visits, active lanes summed over visits, threshold | age << 8}).
+    // Without re-fill (1) the lanes of an 8x8 block walk the tree in lock step — best for camera and
+    // sun-shadow rays (63-81 % of the lanes active per visit) — unless the rays of a block end at very
+    // different times (triangle soups, shuffled rays: 19-37 %), where re-filling below dyn_incoherent busy
+    // lanes is 6-30 % faster.  The measure is only meaningful without re-fill, so a launch that re-fills
+    // keeps doing so for 63 launches and then one launch probes again without.
+    uint32_t dyn_thresh = p.dyn_thresh, dyn_age = 0;
     if (p.dyn_auto && p.stats_prev) {
-        const uint32_t u = p.stats_prev[0], n = p.stats_prev[1];
-        if (n >= 4096u) dyn_thresh = (10ull * u < 3ull * n) ? p.dyn_incoherent : 1u;
+        const uint32_t n = p.stats_prev[1], l = p.stats_prev[2], was = p.stats_prev[3] & 255u, age = p.stats_prev[3] >> 8;
+        if (n >= 4096u && was != 0u) {
+            if (was == 1u) dyn_thresh = (2ull * l < 64ull * n) ? p.dyn_incoherent : 1u;   // under 50 % of the lanes active per visit
+            else if (age < 63u) { dyn_thresh = was; dyn_age = age + 1u; }
+            else dyn_thresh = 1u;
+        }
     }
-    uint32_t stat_inner = 0, stat_uniform = 0;
+    uint32_t stat_inner = 0, stat_uniform = 0, stat_lanes = 0;
     uint32_t phase = PH_IDLE;
     Trav tr;
     tr.cur = REF_NONE; tr.sp = st.sp_init(tid); tr.t = 0; tr.idx = 0; tr.u = tr.v = 0; tr.pf0 = tr.pf1 = 0;
@@ -733,6 +741,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
 #endif
                     stat_uniform += trav_inner_step<COUNT, OCT>(s, tr, st, tid, in, m_in, nbox) ? 1u : 0u;
                     stat_inner += 1u;
+                    stat_lanes += (uint32_t)__popcll(m_in);
                     item_work += 2;
                 }
             };
@@ -808,6 +817,8 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
     if (p.stats_cur && lane == 0 && (blockIdx.x & 7u) == 0u) {   // every 8th workgroup reports
         atomicAdd(&p.stats_cur[0], stat_uniform);
         atomicAdd(&p.stats_cur[1], stat_inner);
+        atomicAdd(&p.stats_cur[2], stat_lanes);
+        p.stats_cur[3] = dyn_thresh | (dyn_age << 8);
     }
 #ifdef RTAMD_EXP_STAMPS
     if (lane == 0 && p.stamps) {

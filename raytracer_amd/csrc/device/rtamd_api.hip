@@ -77,7 +77,7 @@ struct rtamd_context {
     // measured defaults (tools/kbench.py): coherent camera/shadow rays run best without lane
     // re-fill (1), incoherent ray streams with re-fill below 32 busy lanes; leaves are
     // released when 8 lanes wait
-    uint32_t dyn_thresh_fused = 1, dyn_thresh_trace = 32;   // starting values; with dyn_auto the kernel adapts them per launch
+    uint32_t dyn_thresh_fused = 1, dyn_thresh_trace = 1;   // starting values; with dyn_auto the kernel adapts them per launch
     bool dyn_auto = true;
     uint32_t dyn_incoherent = 32;
     uint32_t leaf_thresh = 8;
@@ -223,12 +223,12 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     // (Letting the last wave of a launch zero the counters instead — one exit atomic per wave — was measured
     // equal for the fused shader and 5 % slower for ray_trace launches, whose waves all leave at once.)
     if (ctx->variant == 0) {
-        // One memset per launch zeroes the queue counters and this launch's statistics pair; the pair
+        // One memset per launch zeroes the queue counters and this launch's four statistics words; the four
         // the previous launch wrote sits on the other side of the counters and survives:
         //   [ stats of odd launches | queue counters (n_queues * stride words) | stats of even launches ]
         uint32_t *q = (uint32_t *)sl->queues.p + QUEUE_HEADROOM_WORDS;
         const size_t q_words = (size_t)ctx->n_queues * ctx->queue_stride;
-        uint32_t *stats_odd = q - 2, *stats_even = q + q_words;
+        uint32_t *stats_odd = q - 4, *stats_even = q + q_words;
         const bool odd = (sl->launches & 1u) != 0;
         p.queues = q;
         p.stats_cur = odd ? stats_odd : stats_even;
@@ -236,7 +236,7 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
         sl->launches++;
         sl->stats_mode = mode;
         sl->stats_last = p.stats_cur;
-        HIP_TRY(ctx, hipMemsetAsync(odd ? (void *)stats_odd : (void *)q, 0, (q_words + 2) * sizeof(uint32_t), st));
+        HIP_TRY(ctx, hipMemsetAsync(odd ? (void *)stats_odd : (void *)q, 0, (q_words + 4) * sizeof(uint32_t), st));
     }
     HIP_TRY(ctx, hipEventRecord(sl->ev_start, st));
     if (ctx->variant == 0) {
@@ -405,7 +405,7 @@ int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value) {
     if (!name) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "option name is NULL");
     if (!std::strcmp(name, "dyn_thresh")) {
         if (value < 0 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "dyn_thresh must be 0 (auto) or 1..64");
-        if (value == 0) { ctx->dyn_auto = true; ctx->dyn_thresh_fused = 1; ctx->dyn_thresh_trace = 32; }
+        if (value == 0) { ctx->dyn_auto = true; ctx->dyn_thresh_fused = 1; ctx->dyn_thresh_trace = 1; }
         else { ctx->dyn_auto = false; ctx->dyn_thresh_fused = ctx->dyn_thresh_trace = (uint32_t)value; }
         for (auto &sl : ctx->slots) sl.launches = 0;
     } else if (!std::strcmp(name, "leaf_thresh")) {
@@ -887,15 +887,17 @@ int rtamd_exp_read_stamps(rtamd_context *ctx, unsigned long long *out, uint32_t 
 }
 #endif
 
-int rtamd_last_launch_coherence(rtamd_context *ctx, float *uniform_fraction) {
-    if (!ctx || !uniform_fraction) return RTAMD_ERR_INVALID_ARGUMENT;
+int rtamd_last_launch_coherence(rtamd_context *ctx, float *uniform_fraction, float *lane_utilisation, uint32_t *dyn_thresh_used) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
     const rtamd_context::Slot *sl = nullptr;
     for (const auto &c : ctx->slots) if (c.bound && c.key == ctx->stream && c.ev_valid && c.stats_last) sl = &c;
     if (!sl) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "no persistent-kernel launch on the current stream yet");
     HIP_TRY(ctx, hipEventSynchronize(sl->ev_stop));
-    uint32_t v[2] = {0, 0};
+    uint32_t v[4] = {0, 0, 0, 0};
     HIP_TRY(ctx, hipMemcpy(v, sl->stats_last, sizeof v, hipMemcpyDeviceToHost));
-    *uniform_fraction = v[1] ? (float)v[0] / (float)v[1] : 0.0f;
+    if (uniform_fraction) *uniform_fraction = v[1] ? (float)v[0] / (float)v[1] : 0.0f;
+    if (lane_utilisation) *lane_utilisation = v[1] ? (float)v[2] / (64.0f * (float)v[1]) : 0.0f;
+    if (dyn_thresh_used) *dyn_thresh_used = v[3] & 255u;
     return RTAMD_OK;
 }
 

@@ -69,9 +69,10 @@ class HipRayTracer:
         return ms.value
 
     def last_launch_coherence(self):
-        v = ctypes.c_float()
-        self._check(self._lib.rtamd_last_launch_coherence(self._h, ctypes.byref(v)))
-        return v.value
+        """(wave-uniform share of the node visits, share of lanes active per visit, re-fill threshold used)."""
+        u, l, t = ctypes.c_float(), ctypes.c_float(), ctypes.c_uint32()
+        self._check(self._lib.rtamd_last_launch_coherence(self._h, ctypes.byref(u), ctypes.byref(l), ctypes.byref(t)))
+        return u.value, l.value, t.value
 
     def scene_info(self):
         info = _ffi.SceneInfo()

@@ -307,23 +307,33 @@ def test_full_size_soup_10m_4k(tracer, oracle_a):
 
 
 def test_coherence_feedback_separates_camera_rays_from_soup(tracer, atrium):
-    """dyn_thresh = auto steers by the share of wave-uniform node visits of the previous launch: camera frames of
-    the atrium sit well above the 0.3 switch point, a triangle soup and shuffled rays well below; whatever the
-    threshold in force, outputs do not change."""
+    """dyn_thresh = auto: every launch picks the lane re-fill threshold from what the previous launch on the
+    stream measured (1 -> 32 under 50 % active lanes per visit; 32 is kept for 64 launches, then one probes at 1).  Camera
+    frames of the atrium stay at 1, a triangle soup moves to 32; whatever the threshold, outputs do not change."""
     sc, camera, tex = atrium
     W, H = 640, 360
     inv = camera.inv_proj_view()
+
+    def frames(n, **kw):
+        out, sig = [], []
+        for _ in range(n):
+            out.append(tracer.render(W, H, **kw)["rgba"])
+            sig.append(tracer.last_launch_coherence())
+        for (u, l, t), (_, _, t_next) in zip(sig, sig[1:]):
+            assert t in (1, 32) and (t_next == (32 if l < 0.5 else 1) if t == 1 else t_next in (1, 32)), sig
+        assert all(np.array_equal(bits(out[0]), bits(f)) for f in out[1:])
+        return sig
+
     tracer.set_option("dyn_thresh", 0)
     tracer.upload_scene(sc)
     tracer.upload_texture(0, tex[0]); tracer.upload_texture(1, tex[1])
-    frames = [tracer.render(W, H, camera=(inv, camera.position), has_tex_coords=1, has_normals=1)["rgba"] for _ in range(3)]
-    assert tracer.last_launch_coherence() > 0.4
-    assert all(np.array_equal(bits(frames[0]), bits(f)) for f in frames[1:])
-    tri, pos, cam = scenes.triangle_soup(100_000, seed=5, extent=30.0)
+    sig = frames(4, camera=(inv, camera.position), has_tex_coords=1, has_normals=1)
+    assert all(t == 1 for _, _, t in sig) and sig[-1][0] > 0.4 and sig[-1][1] > 0.5
+    tri, pos, cam = scenes.triangle_soup(400_000, seed=5, extent=30.0)
     m = host.Model.from_arrays(tri, pos)
     m.build_bvh(4)
     tracer.upload_scene(m.scene_arrays())
     c2 = host.Camera(W / H, fov=math.radians(60), position=(0.0, 0.0, -75.0), direction=(0.0, 0.0, 1.0))
-    frames = [tracer.render(W, H, camera=(c2.inv_proj_view(), c2.position))["rgba"] for _ in range(3)]
-    assert tracer.last_launch_coherence() < 0.3
-    assert all(np.array_equal(bits(frames[0]), bits(f)) for f in frames[1:])
+    sig = frames(70, camera=(c2.inv_proj_view(), c2.position))
+    ts = [t for _, _, t in sig]
+    assert sig[0][1] < 0.5 and ts[0] == 1 and all(t == 32 for t in ts[1:65]) and ts[65] == 1 and ts[66] == 32

@@ -83,7 +83,7 @@ def main():
                     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 24 * 1e3
                 if r >= 2:
                     res[name].append(dt)
-                coh[name] = tr.last_launch_coherence() if int(o.get("variant", 0)) == 0 else -1.0
+                coh[name] = tr.last_launch_coherence() if int(o.get("variant", 0)) == 0 else (-1.0, -1.0, 0)
                 continue
             for _ in range(3):   # the schedule of a launch comes from the previous launch of the same arm
                 if mode == "fused":
@@ -98,7 +98,7 @@ def main():
     lib = os.environ.get("RTAMD_DEVICE_LIB", "default")
     for name, _ in arms:
         v = np.array(res[name])
-        print(json.dumps({"lib": os.path.basename(lib), "arm": name, "median_ms": round(float(np.median(v)), 4), "min_ms": round(float(v.min()), 4), "coherence": round(coh.get(name, -1.0), 3)}))
+        print(json.dumps({"lib": os.path.basename(lib), "arm": name, "median_ms": round(float(np.median(v)), 4), "min_ms": round(float(v.min()), 4), "uniform": round(coh[name][0], 3), "lane_util": round(coh[name][1], 3), "dyn_thresh": coh[name][2]}))
 
 
 if __name__ == "__main__":
