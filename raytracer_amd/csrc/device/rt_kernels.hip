@@ -174,7 +174,8 @@ struct Trav {
     uint32_t idx;
     float u, v;
     uint32_t cur;   // node reference being visited, REF_NONE when the traversal is finished
-    uint32_t sp;    // number of deferred references on this lane's stack
+    uint32_t sp;    // deferred references on this lane's stack (Stack policy's representation)
+    uint32_t sb;    // StackGlobal: entries moved out to HBM (same representation); else unused
     uint32_t pf0, pf1;  // landing registers of the prefetch touches (kept live until the next visit)
 };
 
@@ -182,20 +183,24 @@ struct Trav {
 // bank = tid % 32, conflict-free whatever the depths of the lanes).  Deeper entries
 // spill: StackScratch to a private (scratch) array, StackGlobal to the wave slot's
 // slice of an HBM buffer laid out [entry][lane] so that a spill is one coalesced line.
-// `sp` is opaque to the traversal code: StackScratch counts entries, StackGlobal keeps the
-// LDS byte offset of the next free slot (entry*BLOCK*4 + tid*4), which is the ds_read/
-// ds_write address itself and makes "empty" and "in LDS" compares against constants.
+// `sp` / `sb` are opaque to the traversal code.  StackScratch counts entries (sb unused).
+// StackGlobal keeps the TOP LDS_STACK_ENTRIES entries of a lane's stack in LDS, as a ring: sp is
+// depth*STEP + tid*4, whose low bits (sp & RING_MASK) are the ds_read/ds_write address of the next
+// free slot; sb = (number of bottom entries moved out to HBM)*STEP.  A push into a full ring first
+// moves the oldest ring entry to the lane's HBM column; a pop from an empty ring reads the HBM
+// column directly.  Deep trees (triangle soup: 30+ levels) thus keep their hot entries in LDS —
+// with a fixed bottom-16 layout the 1 M-triangle soup was 17 % slower than with 24 LDS entries.
 struct StackScratch {
     uint32_t *lds;
     uint32_t spill[SPILL_STACK_ENTRIES];
     __device__ __forceinline__ uint32_t sp_init(uint32_t) const { return 0u; }
     __device__ __forceinline__ bool empty(uint32_t sp) const { return sp == 0u; }
-    __device__ __forceinline__ void push(uint32_t tid, uint32_t &sp, uint32_t v) {
+    __device__ __forceinline__ void push(uint32_t tid, uint32_t &sp, uint32_t &, uint32_t v) {
         if (__builtin_expect(sp < (uint32_t)LDS_STACK_ENTRIES, 1)) lds[sp * BLOCK + tid] = v;
         else if (sp < (uint32_t)MAX_STACK_ENTRIES) spill[sp - LDS_STACK_ENTRIES] = v;
         sp++;
     }
-    __device__ __forceinline__ uint32_t pop(uint32_t tid, uint32_t &sp) const {
+    __device__ __forceinline__ uint32_t pop(uint32_t tid, uint32_t &sp, uint32_t &) const {
         sp--;
         if (__builtin_expect(sp < (uint32_t)LDS_STACK_ENTRIES, 1)) return lds[sp * BLOCK + tid];
         if (sp < (uint32_t)MAX_STACK_ENTRIES) return spill[sp - LDS_STACK_ENTRIES];
@@ -206,25 +211,34 @@ struct StackGlobal {
     uint32_t *lds;
     uint32_t *spill;  // this lane's column: entry e at spill[e * 64]
     static constexpr uint32_t STEP = BLOCK * 4u;
+    static constexpr uint32_t RING = LDS_STACK_ENTRIES * STEP;
+    static_assert((LDS_STACK_ENTRIES & (LDS_STACK_ENTRIES - 1)) == 0, "ring addressing needs a power-of-two entry count");
+    __device__ __forceinline__ uint32_t lds_word(uint32_t off) const { return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds) + (off & (RING - 1u))); }
+    __device__ __forceinline__ void lds_word(uint32_t off, uint32_t v) const { *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + (off & (RING - 1u))) = v; }
     __device__ __forceinline__ uint32_t sp_init(uint32_t tid) const { return tid * 4u; }
     __device__ __forceinline__ bool empty(uint32_t sp) const { return sp < STEP; }
-    __device__ __forceinline__ void push(uint32_t, uint32_t &sp, uint32_t v) {
-        if (__builtin_expect(sp < LDS_STACK_ENTRIES * STEP, 1)) *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + sp) = v;
-        else if (sp < MAX_STACK_ENTRIES * STEP) spill[(sp / STEP - LDS_STACK_ENTRIES) * 64u] = v;
+    __device__ __forceinline__ void push(uint32_t, uint32_t &sp, uint32_t &sb, uint32_t v) {
+        if (__builtin_expect(sp - sb >= RING, 0)) {   // ring full: its oldest entry goes to HBM
+            const uint32_t e = sb / STEP;
+            if (e < (uint32_t)SPILL_STACK_ENTRIES) spill[e * 64u] = lds_word(sp);   // slot (sp & mask) holds entry sb
+            sb += STEP;
+        }
+        lds_word(sp, v);
         sp += STEP;
     }
-    __device__ __forceinline__ uint32_t pop(uint32_t, uint32_t &sp) const {
+    __device__ __forceinline__ uint32_t pop(uint32_t, uint32_t &sp, uint32_t &sb) const {
         sp -= STEP;
-        if (__builtin_expect(sp < LDS_STACK_ENTRIES * STEP, 1)) return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds) + sp);
-        if (sp < MAX_STACK_ENTRIES * STEP) return spill[(sp / STEP - LDS_STACK_ENTRIES) * 64u];
-        return REF_NONE;
+        if (__builtin_expect(sp >= sb, 1)) return lds_word(sp);   // sp - sb carries + tid*4, so >= means "entry sp is in the ring"
+        sb -= STEP;                                               // ring empty: the top entry is the last one moved out
+        const uint32_t e = sb / STEP;
+        return e < (uint32_t)SPILL_STACK_ENTRIES ? spill[e * 64u] : REF_NONE;
     }
 };
 
 // Start a traversal: the root box is tested once (:115-117).
 template <bool COUNT>
 __device__ __forceinline__ void trav_begin(const SceneDev &s, Trav &tr, float t0, uint32_t sp0, uint32_t &nbox) {
-    tr.t = t0; tr.idx = 0; tr.u = 0.0f; tr.v = 0.0f; tr.sp = sp0;
+    tr.t = t0; tr.idx = 0; tr.u = 0.0f; tr.v = 0.0f; tr.sp = sp0; tr.sb = 0;
     if (COUNT) nbox++;
     float d = aabb_dist(tr.ray, s.root_box[0], s.root_box[1], s.root_box[2], s.root_box[3], s.root_box[4], s.root_box[5], tr.t);
     tr.cur = (d == MISS) ? REF_NONE : s.root_ref;
@@ -273,9 +287,9 @@ __device__ __forceinline__ void trav_select(Trav &tr, Stack &st, uint32_t tid, b
     const bool a_first = hit0 && (!hit1 || tmin0 < tmin1);
     const uint32_t near_ref = a_first ? ref_a : ref_b;
     const uint32_t far_ref = a_first ? ref_b : ref_a;
-    if (hit0 && hit1) st.push(tid, tr.sp, far_ref);
+    if (hit0 && hit1) st.push(tid, tr.sp, tr.sb, far_ref);
     if (hit0 || hit1) tr.cur = near_ref;
-    else tr.cur = st.empty(tr.sp) ? REF_NONE : st.pop(tid, tr.sp);
+    else tr.cur = st.empty(tr.sp) ? REF_NONE : st.pop(tid, tr.sp, tr.sb);
 }
 
 // Touch-prefetch: one dword load from the record a child reference points to (node
@@ -362,7 +376,7 @@ __device__ __forceinline__ void trav_leaf(const SceneDev &s, Trav &tr, const Sta
     if (COUNT) ntri += count;
     for (uint32_t i = first; i < first + count; i++) tri_test(tr.ray, s.tris, i, tr.t, tr.idx, tr.u, tr.v);
     if (occlusion && tr.t < T_HIT_LIMIT) { tr.cur = REF_NONE; return; }
-    tr.cur = st.empty(tr.sp) ? REF_NONE : st.pop(tid, tr.sp);
+    tr.cur = st.empty(tr.sp) ? REF_NONE : st.pop(tid, tr.sp, tr.sb);
 }
 
 __device__ __forceinline__ bool ref_is_inner(uint32_t ref) { return (ref & REF_LEAF_BIT) == 0 && ref != REF_NONE; }
@@ -621,7 +635,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
     uint32_t stat_inner = 0, stat_uniform = 0, stat_lanes = 0;
     uint32_t phase = PH_IDLE;
     Trav tr;
-    tr.cur = REF_NONE; tr.sp = st.sp_init(tid); tr.t = 0; tr.idx = 0; tr.u = tr.v = 0; tr.pf0 = tr.pf1 = 0;
+    tr.cur = REF_NONE; tr.sp = st.sp_init(tid); tr.sb = 0; tr.t = 0; tr.idx = 0; tr.u = tr.v = 0; tr.pf0 = tr.pf1 = 0;
     tr.ray = Ray{0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t out_index = 0;
     uint32_t nbox = 0, ntri = 0;
