@@ -96,6 +96,84 @@ def test_big_leaves_use_the_overflow_table(tracer, oracle_a):
     assert np.array_equal(bits(tracer.trace(org, d)), bits(oracle_a.trace(sc, org, d)["hits"]))
 
 
+def _chain_scene(depth):
+    """Hand-made BVH in the reference's buffer format (types.rs:101-109): a chain of `depth` inner
+    nodes, node k = {leaf of the plane triangle at z = k, rest of the chain}.  A ray travelling
+    towards -z enters the rest first at every level and defers the leaf: `depth` stacked entries."""
+    n_tri = depth + 1
+    pos = np.concatenate([np.float32([[-3, -3, z], [3, -3, z], [0, 3, z]]) for z in range(n_tri)])
+    tri = np.array([[3 * i, 3 * i + 1, 3 * i + 2, 0] for i in range(n_tri)], np.uint32).view(host.TRIANGLE_DTYPE).reshape(-1)
+    nodes = np.zeros(2 * depth + 1, host.NODE_DTYPE)
+    for k in range(depth):
+        nodes[2 * k] = ((-3, -3, k, 3, 3, depth), 0, 2 * k + 1, 2 * k + 2)
+        nodes[2 * k + 1] = ((-3, -3, k, 3, 3, k), 1, k, 1)
+    nodes[2 * depth] = ((-3, -3, depth, 3, 3, depth), 1, depth, 1)
+    return {"nodes": nodes, "triangles": tri, "positions": pos, "tex_coords": None, "normals": None}
+
+
+@pytest.mark.parametrize("depth", [17, 40, 99])
+def test_deep_traversal_stack_matches_oracle(tracer, oracle_a, depth):
+    """Stacks deeper than the 16 entries held in LDS: the oldest entries move out to the HBM
+    columns and come back on the way up (rt_kernels.hip StackGlobal).  Rays towards -z stack one
+    entry per level, rays towards +z none, oblique rays something in between, so the lanes of a
+    wave sit at different depths.  Both kernel variants, hit records bit-exact.  99 levels is the
+    deepest chain the shader's 100-entry stack (ray_trace_and_shade.frag:12) holds: it pushes both
+    children before it pops the nearer one."""
+    sc = _chain_scene(depth)
+    tracer.upload_scene(sc)
+    assert tracer.scene_info().max_depth == depth
+    rng = np.random.default_rng(depth)
+    n = 4096
+    xy = rng.uniform(-3.5, 3.5, (n, 2))
+    down = np.concatenate([xy, np.full((n, 1), depth + 5.0)], 1), np.tile([0.0, 0.0, -1.0], (n, 1))
+    up = np.concatenate([xy, np.full((n, 1), -5.0)], 1), np.tile([0.0, 0.0, 1.0], (n, 1))
+    o3 = np.concatenate([rng.uniform(-4, 4, (n, 2)), rng.choice([-5.0, depth + 5.0], (n, 1))], 1)
+    tgt = np.concatenate([rng.uniform(-3, 3, (n, 2)), rng.uniform(0, depth, (n, 1))], 1)
+    d3 = tgt - o3
+    d3 /= np.linalg.norm(d3, axis=1, keepdims=True)
+    org = np.concatenate([down[0], up[0], o3]).astype(np.float32)
+    d = np.concatenate([down[1], up[1], d3]).astype(np.float32)
+    perm = rng.permutation(len(org))                      # mix the three kinds inside every wave
+    org, d = org[perm], d[perm]
+    want = oracle_a.trace(sc, org, d, nthreads=8)["hits"]
+    assert (want[:, 0] < 1e30).mean() > 0.4
+    try:
+        for variant in (0, 1):
+            tracer.set_kernel_variant(variant)
+            assert np.array_equal(bits(tracer.trace(org, d)), bits(want)), variant
+    finally:
+        tracer.set_kernel_variant(0)
+    a = oracle_a.render(sc, d, org, 0, 0, nthreads=8)
+    r = tracer.render(len(org), 1, dir=d, org=org, has_tex_coords=0, has_normals=0)
+    assert np.array_equal(a["hit_id"], r["hit_id"]) and np.array_equal(bits(a["hit_t"]), bits(r["hit_t"]))
+    assert rgb_err_255(a["rgba"], r["rgba"]).max() <= 0.05
+
+
+def test_deepest_accepted_tree_and_rejection_beyond(tracer):
+    """128 levels (beyond the shader's own stack, so no oracle): 112 entries per lane pass through the
+    HBM columns.  The two kernel variants keep their stacks differently (LDS ring + HBM columns /
+    LDS + private scratch) and must agree bit for bit; rays straight down hit the top plane at t = 5."""
+    depth = 128
+    tracer.upload_scene(_chain_scene(depth))
+    rng = np.random.default_rng(7)
+    n = 8192
+    org = np.concatenate([rng.uniform(-3.5, 3.5, (n, 2)), np.full((n, 1), depth + 5.0)], 1).astype(np.float32)
+    d = np.tile(np.float32([0, 0, -1]), (n, 1))
+    d[1::2] = np.float32([0.01, 0.02, -1]) / np.linalg.norm([0.01, 0.02, -1]).astype(np.float32)
+    got = tracer.trace(org, d)
+    try:
+        tracer.set_kernel_variant(1)
+        assert np.array_equal(bits(tracer.trace(org, d)), bits(got))
+    finally:
+        tracer.set_kernel_variant(0)
+    inside = (np.abs(org[::2, 0]) < 1.0) & (np.abs(org[::2, 1]) < 0.9)
+    assert inside.sum() > 100
+    assert np.all(got[::2][inside, 0] == 5.0) and np.all(bits(got[::2])[inside, 3] == depth)
+    with pytest.raises(RtamdError) as e:
+        tracer.upload_scene(_chain_scene(129))
+    assert e.value.code == -4 and "depth" in str(e.value)
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_tile_shards_assemble_to_the_full_frame(tracer, world):
     g = load_golden("bunny")
