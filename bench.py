@@ -11,7 +11,7 @@ frame is split into interleaved 32x32 tiles (scene replicated), every rank
 renders its tiles, one RCCL gather brings them to rank 0, which assembles the
 scan-line frame — all inside the timed step.
 
-Frames in flight (default 2): consecutive frames are issued on alternating HIP
+Frames in flight (default 4, 8 with N > 1): consecutive frames are issued round-robin on HIP
 streams (the library keeps per-stream launch scratch, include/rtamd.h), each into
 its own output buffer, so the slow tail of frame k overlaps the start of frame
 k+1 — how a real-time renderer submits frames.  All K frames complete inside the
@@ -30,6 +30,15 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+
+# Frames in flight need hardware queues of their own: HIP spreads a process's streams over
+# GPU_MAX_HW_QUEUES queues (default 4) and launches on streams that share one do not overlap.
+# Measured (tools/launch_cost.py, one rank's 1/8 share of the frame): 65 us per frame with 4
+# queues / 6 streams, 42 us with 16 queues / 8 streams.  Read by the HIP runtime when it starts;
+# the GPU boxes export 4, so this replaces the value (RTAMD_BENCH_HW_QUEUES overrides, "0" keeps it).
+_hwq = os.environ.get("RTAMD_BENCH_HW_QUEUES", "16")
+if _hwq != "0":
+    os.environ["GPU_MAX_HW_QUEUES"] = str(max(1, min(32, int(_hwq))))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 VALU_PEAK_TOPS = 78.6        # 157.3 TFLOP/s FMA-counted fp32 vector = 78.6 T un-fused op/s
@@ -90,7 +99,7 @@ def main():
     ap.add_argument("--workload", default="atrium_1080p")
     ap.add_argument("--variant", type=int, default=0, help="0 persistent (default), 1 static A/B baseline")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="frames issued round-robin on that many streams (1 = serial; 0 = auto: 2 on one GPU, 6 with tiles split over "
+                    help="frames issued round-robin on that many streams (1 = serial; 0 = auto: 4 on one GPU, 8 with tiles split over "
                          "several GPUs, where a launch covers 1/N of the frame and is bounded by its slowest rays, not by throughput)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -145,7 +154,12 @@ def main():
 
     per_rank_tiles = tracer.tiles_per_rank(W, H, world)
     n_local_out = n_px if world == 1 else per_rank_tiles * TILE_PIXELS
-    F = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world == 1 else 6)
+    # auto: 4 frames in flight on one GPU (8 with N > 1, where a launch covers 1/N of the frame and is bounded by
+    # its slowest rays); 2 when the scene records exceed the 256 MB Infinity Cache, where more frames in
+    # flight only evict each other's nodes (10 M soup: 4.04 ms with 2, 4.30 ms with 4)
+    info = tracer.scene_info()
+    scene_mb = (info.inner_node_count * 64 + info.triangle_count * 48) / 1e6
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (2 if scene_mb > 256 else 4 if world == 1 else 8)
     F = max(1, min(8, F))
     # frame k renders on render_streams[k % F] into rgba[k % F]; gather + assembly stay on `stream`
     render_streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(F - 1)]

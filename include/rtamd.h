@@ -78,7 +78,10 @@ const char *rtamd_last_error(const rtamd_context *ctx);
  * separate launch scratch (queue counters, stack-spill area, timing events) per stream for
  * up to 8 streams, so a caller pipelines frames by alternating two streams of its own:
  *     set_stream(s[k % 2]); rtamd_render_device(..., out[k % 2]);
- * and orders consumers with ordinary stream/event dependencies.  A ninth stream takes over
+ * and orders consumers with ordinary stream/event dependencies.  Streams overlap only when
+ * they sit on different hardware queues: HIP spreads a process's streams over
+ * GPU_MAX_HW_QUEUES queues (default 4; read once when the runtime starts), so set it to 16 in
+ * the environment when more than two frames are in flight.  A ninth stream takes over
  * the least recently used scratch after that one's last launch has finished.  Synchronize a
  * stream before destroying it.  (The reference's passes are serialised by the GL command
  * stream, src/main.rs:143-230; this has no counterpart there.) */
@@ -286,6 +289,8 @@ int rtamd_set_kernel_variant(rtamd_context *ctx, int variant);
  *                       current item has cost this many loop-iteration units (again at x3, x7);
  *  "adaptive_order" 0/1 schedule a frame's items by the cost counted for them in the previous
  *                       launch of the same size, longest first (default 0: measured slower);
+ *  "launch_timing" 0/1  record a start event in front of every launch (default 1); 0 saves one
+ *                        stream operation per launch, rtamd_last_kernel_ms then reports an error.
  *  "shadow_anyhit" 0/1  fused shader only (default 1): a shadow ray stops at the first leaf that
  *                       leaves its t below the 1000 limit.  The reference traverses on
  *                       (ray_trace_and_shade.frag:213-219) but consumes only `shadow_t < 1000`, which

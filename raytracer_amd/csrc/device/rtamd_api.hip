@@ -42,6 +42,7 @@ struct rtamd_context {
         uint64_t last_use = 0;
         hipEvent_t ev_start = nullptr, ev_stop = nullptr;
         bool ev_valid = false;
+        bool timed = false;   // ev_start was recorded for the last launch
         DevBuf queues, spill;
         uint64_t launches = 0;              // persistent-kernel launches on this stream since the statistics layout last changed
         int stats_mode = -1;                // mode of the launch that wrote the latest statistics
@@ -83,6 +84,7 @@ struct rtamd_context {
     uint32_t leaf_thresh = 8;
     uint32_t prio_thresh = 0;
     bool shadow_anyhit = true;
+    bool launch_timing = true;        // record a start event per launch (rtamd_last_kernel_ms); the stop event is always recorded
     uint32_t heavy_num = 8;   // adaptive_order: items costing >= heavy_num/4 x mean go first
     uint32_t queue_stride = 64, chunk = 1;
     uint32_t max_blocks_per_cu = 0;   // 0 = as many as fit (8 workgroups = 8 waves per SIMD)
@@ -238,7 +240,8 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
         sl->stats_last = p.stats_cur;
         HIP_TRY(ctx, hipMemsetAsync(odd ? (void *)stats_odd : (void *)q, 0, (q_words + 4) * sizeof(uint32_t), st));
     }
-    HIP_TRY(ctx, hipEventRecord(sl->ev_start, st));
+    sl->timed = ctx->launch_timing;
+    if (sl->timed) HIP_TRY(ctx, hipEventRecord(sl->ev_start, st));
     if (ctx->variant == 0) {
         int per_cu = ctx->persistent_blocks_per_cu[mode * 2 + (count ? 1 : 0)];
         if (ctx->max_blocks_per_cu && (int)ctx->max_blocks_per_cu < per_cu) per_cu = (int)ctx->max_blocks_per_cu;
@@ -430,6 +433,8 @@ int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value) {
     } else if (!std::strcmp(name, "heavy_factor_x4")) {
         if (value < 0 || value > 1024) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "heavy_factor_x4 must be 0..1024");
         ctx->heavy_num = (uint32_t)value;
+    } else if (!std::strcmp(name, "launch_timing")) {
+        ctx->launch_timing = value != 0;
     } else if (!std::strcmp(name, "shadow_anyhit")) {
         ctx->shadow_anyhit = value != 0;
     } else if (!std::strcmp(name, "adaptive_order")) {
@@ -908,6 +913,7 @@ int rtamd_last_kernel_ms(rtamd_context *ctx, float *ms) {
     for (const auto &c : ctx->slots) if (c.bound && c.key == ctx->stream && c.ev_valid) sl = &c;
     if (!sl && ctx->last_slot >= 0 && ctx->slots[ctx->last_slot].ev_valid) sl = &ctx->slots[ctx->last_slot];
     if (!sl) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "no kernel has been launched yet");
+    if (!sl->timed) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "the last launch was not timed (option launch_timing is 0)");
     HIP_TRY(ctx, hipEventSynchronize(sl->ev_stop));
     HIP_TRY(ctx, hipEventElapsedTime(ms, sl->ev_start, sl->ev_stop));
     return RTAMD_OK;

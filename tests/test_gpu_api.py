@@ -66,6 +66,23 @@ def test_errors():
         t.close()
 
 
+def test_launch_timing_option(tracer):
+    g = load_golden("cube")
+    tracer.upload_scene(g["scene"])
+    org = np.zeros((64, 3), np.float32); d = np.tile(np.float32([0, 0, -1]), (64, 1))
+    want = tracer.trace(org, d)
+    assert tracer.last_kernel_ms() > 0
+    try:
+        tracer.set_option("launch_timing", 0)
+        assert np.array_equal(bits(tracer.trace(org, d)), bits(want))
+        with pytest.raises(RtamdError):
+            tracer.last_kernel_ms()
+    finally:
+        tracer.set_option("launch_timing", 1)
+    tracer.trace(org, d)
+    assert tracer.last_kernel_ms() > 0
+
+
 def test_scene_info_and_single_leaf_root(tracer):
     pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
     m = host.Model.from_arrays(np.array([[0, 1, 2, 0]], np.uint32), pos)

@@ -11,10 +11,13 @@ n = W * H
 d_dir = torch.empty((n, 3), dtype=torch.float32, device=dev); tr.generate_rays_device(W, H, camera.inv_proj_view(), d_dir.data_ptr())
 d_org = torch.tensor(np.asarray(camera.position, np.float32), device=dev).repeat(n, 1).contiguous()
 streams = [torch.cuda.Stream(device=dev) for _ in range(8)]
+timing = int(os.environ.get("LAUNCH_TIMING", "1"))
+tr.set_option("launch_timing", timing)
+print("launch_timing", timing)
 for world in (1, 2, 4, 8):
     per = tr.tiles_per_rank(W, H, world) * 1024
     outs = [torch.zeros((per if world > 1 else n, 4), dtype=torch.float32, device=dev) for _ in range(8)]
-    for S in (1, 2, 6):
+    for S in (1, 2, 4, 6, 8):
         K = 400
         for rep in range(2):
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -23,4 +26,4 @@ for world in (1, 2, 4, 8):
                 tr.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=True, has_normals=True, tile_rank=3 % world, tile_world=world, rgba_ptr=outs[k % S].data_ptr())
             t_cpu = time.perf_counter() - t0
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(f"tile_world {world} streams {S}: {dt / K * 1e6:.1f} us per frame (CPU issue {t_cpu / K * 1e6:.1f} us), last kernel {tr.last_kernel_ms()*1e3:.1f} us", flush=True)
+        print(f"tile_world {world} streams {S}: {dt / K * 1e6:.1f} us per frame (CPU issue {t_cpu / K * 1e6:.1f} us), last kernel {tr.last_kernel_ms()*1e3 if timing else -1:.1f} us", flush=True)

@@ -19,6 +19,16 @@ __global__ void k(float *out, int iters) {
                 else if (OP == 5) a[i] = (a[i] < b) ? a[(i + 1) & 7] : c;            // v_cmp + v_cndmask
                 else if (OP == 6) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 7]));
             }
+            if (OP >= 7) {   // packed fp32: 4 chains of float2 (two results per instruction)
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                f2 *p = reinterpret_cast<f2 *>(a);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (OP == 7) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(p[i]) : "v"(p[i]), "v"(p[(i + 1) & 3]));
+                    else if (OP == 8) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(p[i]) : "v"(p[i]), "v"(p[(i + 1) & 3]));
+                    else if (OP == 9) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(p[i]) : "v"(p[i]), "v"(p[(i + 1) & 3]));
+                }
+            }
         }
     }
     float s = 0;
@@ -41,5 +51,6 @@ int main() {
     float *out; if (hipMalloc(&out, 256 * 8 * 256 * 4) != hipSuccess) return 1;
     run<0>("v_mul_f32", out, 128); run<1>("v_sub_f32", out, 128); run<2>("v_min/max_f32", out, 128); run<3>("mul,sub,min,max mix", out, 128);
     run<4>("v_max3_f32", out, 128); run<5>("v_cmp + v_cndmask (2 instr)", out, 256); run<6>("v_mov_b32", out, 128);
+    run<7>("v_pk_mul_f32 (2 results)", out, 64); run<8>("v_pk_add_f32 (2 results)", out, 64); run<9>("v_pk_add_f32 neg+op_sel", out, 64);
     return 0;
 }

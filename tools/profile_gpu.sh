@@ -6,6 +6,8 @@ set -e -o pipefail
 tag=$1; shift
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
+# under rocprofv3 the HIP runtime starts before bench.py can set this (bench.py: frames in flight need their own queues)
+export GPU_MAX_HW_QUEUES=16
 out=gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline "$@" > "$out/trace.log" 2>&1
