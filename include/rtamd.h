@@ -117,12 +117,37 @@ typedef struct rtamd_scene_desc {
  * Replaces ShaderStorageBuffer::new + buffer_data (src/gl_wrapper/buffer.rs:84-108). */
 int rtamd_upload_scene(rtamd_context *ctx, const rtamd_scene_desc *scene);
 
-/* Albedo texture for material slot 0 or 1 (modelTextures[2],
- * ray_trace_and_shade.frag:21): tightly packed RGB8 rows, first row first, as
+/* Albedo texture for a slot: tightly packed RGB8 rows, first row first, as
  * Texture::from_data hands them to glTexImage2D (src/gl_wrapper/texture.rs:11-26,
  * 65-79).  Sampling is LINEAR min/mag, REPEAT wrap, no mip maps, RGBA8 unorm.
- * A slot never uploaded samples as opaque white. */
+ * A slot never uploaded samples as opaque white.  Slots 0 and 1 are the shader's
+ * modelTextures[2] (ray_trace_and_shade.frag:21), selected by the triangle's material
+ * index; slots 2..RTAMD_MAX_TEXTURE_SLOTS-1 are reachable only through a material table
+ * (rtamd_upload_materials). */
+#define RTAMD_MAX_TEXTURE_SLOTS 16
 int rtamd_upload_texture(rtamd_context *ctx, uint32_t slot, const uint8_t *rgb8, uint32_t width, uint32_t height);
+
+/* Per-material shading for the fused render.  The reference parses
+ * Ka / Kd / Ks / Ns and map_Kd into Material (src/rendering/material.rs:5-16,
+ * resource_parser.rs:49-109) but its shader ignores them: AMBIENT 0.5, DIFFUSE 0.8,
+ * SPECULAR 0.4, SPEC_POW 30 are constants (ray_trace_and_shade.frag:184-187) and only two
+ * textures exist (:21).  With a table, pixel shading uses the hit triangle's material
+ * (mat_idx, src/raytracing/types.rs:4-9) in the constants' places, component-wise:
+ *     ambient  = albedo * skybox(n) * ambient_color
+ *     diffuse  = albedo * SUN_COL * clamp(dot(n, SUN_DIR)) * diffuse_color
+ *     specular = SUN_COL * clamp(pow(dot(reflected, SUN_DIR), specular_exp)) * specular_color
+ * with albedo from texture_slot (-1: none = white).  The expressions are the shader's own
+ * (:222-224), so a table of {0.5, 0.8, 0.4, 30, slot = material index} entries reproduces
+ * the reference output bit for bit (tested); any other table has no reference output to
+ * compare with and is checked against the CPU oracle only.
+ * `count` must exceed every mat_idx of the uploaded scene; count 0 removes the table.
+ * Uploading a scene removes the table.  No counterpart in the reference's shader inputs. */
+typedef struct rtamd_shading_material {
+    float ambient_color[3], diffuse_color[3], specular_color[3];   /* Ka, Kd, Ks */
+    float specular_exp;                                            /* Ns */
+    int32_t texture_slot;                                          /* map_Kd: 0..RTAMD_MAX_TEXTURE_SLOTS-1, or -1 */
+} rtamd_shading_material;
+int rtamd_upload_materials(rtamd_context *ctx, const rtamd_shading_material *materials, uint32_t count);
 
 /* ---- fused render: ray_trace_and_shade.frag:main (:195-235) --------------- */
 

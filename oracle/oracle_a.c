@@ -256,8 +256,14 @@ typedef struct {
     int overflow;
 } oa_pixel;
 
+/* Per-material shading (include/rtamd.h rtamd_upload_materials): the MTL
+ * quantities of src/rendering/material.rs:5-16 in the places of the shader's constants.  Same field
+ * order as rtamd_shading_material.  No reference output exists for a table other than the constants. */
+typedef struct { float ka[3], kd[3], ks[3], ns; int32_t tex_slot; } oa_material;
+#define OA_MAX_TEXTURE_SLOTS 16
+
 static void oa_shade_pixel(const oa_scene *sc, v3 dir, v3 org, int has_texcoords, int has_normals,
-                           const oa_texture tex[2], oa_pixel *px) {
+                           const oa_texture tex[2], const oa_material *mats, const oa_texture *slots, oa_pixel *px) {
     float t = 1000000.0f;
     uint32_t tri = 0;
     v2 uv = { 0, 0 };
@@ -283,10 +289,25 @@ static void oa_shade_pixel(const oa_scene *sc, v3 dir, v3 org, int has_texcoords
         int shadow = shadow_t < 1000.0f;
         px->shadow = shadow;
         uint32_t mat = sc->triangles[tri].mat;
-        v3 albedo = oa_sample_albedo(&tex[mat & 1u], tc.x, -tc.y);
-        v3 ambient = oa_scale(oa_mulv(albedo, oa_skybox(normal)), AMBIENT);
-        v3 diffuse = oa_scale(oa_scale(oa_mulv(albedo, SUN_COL), oa_clamp01(oa_dot(normal, sd))), DIFFUSE);
-        v3 specular = oa_scale(oa_scale(SUN_COL, oa_pow_clamp01(oa_dot(reflected, sd), SPEC_POW)), SPECULAR);
+        v3 ka = { AMBIENT, AMBIENT, AMBIENT }, kd = { DIFFUSE, DIFFUSE, DIFFUSE }, ks = { SPECULAR, SPECULAR, SPECULAR };
+        float ns = SPEC_POW;
+        v3 albedo;
+        if (mats) {
+            static const uint8_t white_rgb[3] = { 255, 255, 255 };
+            const oa_texture white = { white_rgb, 1, 1 };
+            const oa_material *m = &mats[mat];
+            ka.x = m->ka[0]; ka.y = m->ka[1]; ka.z = m->ka[2];
+            kd.x = m->kd[0]; kd.y = m->kd[1]; kd.z = m->kd[2];
+            ks.x = m->ks[0]; ks.y = m->ks[1]; ks.z = m->ks[2];
+            ns = m->ns;
+            const oa_texture *t = (m->tex_slot >= 0 && slots[m->tex_slot].rgb) ? &slots[m->tex_slot] : &white;
+            albedo = oa_sample_albedo(t, tc.x, -tc.y);
+        } else {
+            albedo = oa_sample_albedo(&tex[mat & 1u], tc.x, -tc.y);
+        }
+        v3 ambient = oa_mulv(oa_mulv(albedo, oa_skybox(normal)), ka);
+        v3 diffuse = oa_mulv(oa_scale(oa_mulv(albedo, SUN_COL), oa_clamp01(oa_dot(normal, sd))), kd);
+        v3 specular = oa_mulv(oa_scale(SUN_COL, oa_pow_clamp01(oa_dot(reflected, sd), ns)), ks);
         if (shadow) { diffuse = oa_scale(diffuse, 0.0f); specular = oa_scale(specular, 0.0f); }
         col = oa_add(oa_add(ambient, diffuse), specular);
     } else {
@@ -306,6 +327,7 @@ typedef struct {
     const float *dir, *org;
     int has_tc, has_n;
     oa_texture tex[2];
+    const oa_material *mats; const oa_texture *slots;   /* NULL: the shader's constants and modelTextures[2] */
     float *rgba; uint32_t *hit_id; float *hit_t; uint32_t *counts; int8_t *shadow;
     float *hits; /* trace mode */
     int mode;    /* 0 render, 1 trace */
@@ -320,7 +342,7 @@ static void *oa_worker(void *arg) {
         v3 org = { j->org[3 * i], j->org[3 * i + 1], j->org[3 * i + 2] };
         if (j->mode == 0) {
             oa_pixel px;
-            oa_shade_pixel(j->sc, dir, org, j->has_tc, j->has_n, j->tex, &px);
+            oa_shade_pixel(j->sc, dir, org, j->has_tc, j->has_n, j->tex, j->mats, j->slots, &px);
             if (px.overflow) j->overflow = 1;
             if (j->rgba) memcpy(j->rgba + 4 * i, px.rgba, 16);
             if (j->hit_id) j->hit_id[i] = px.hit_id;
@@ -390,6 +412,23 @@ int oa_render(const oa_scene *sc, uint64_t n, const float *dir, const float *org
     j.sc = sc; j.n = n; j.dir = dir; j.org = org; j.has_tc = has_texcoords; j.has_n = has_normals;
     j.tex[0].rgb = tex0; j.tex[0].w = tw0; j.tex[0].h = th0;
     j.tex[1].rgb = tex1; j.tex[1].w = tw1; j.tex[1].h = th1;
+    j.rgba = rgba; j.hit_id = hit_id; j.hit_t = hit_t; j.counts = counts; j.shadow = shadow; j.mode = 0;
+    return run_jobs(&j, nthreads);
+}
+
+/* The fused shader with a material table: n_mats entries (every triangle's mat must be < n_mats,
+ * else -2), textures[OA_MAX_TEXTURE_SLOTS] with rgb == NULL for an empty slot (samples white). */
+int oa_render_materials(const oa_scene *sc, uint64_t n, const float *dir, const float *org, int has_texcoords, int has_normals,
+                        const oa_material *mats, uint32_t n_mats, const uint8_t *const *tex_rgb, const int *tex_w, const int *tex_h,
+                        float *rgba, uint32_t *hit_id, float *hit_t, uint32_t *counts, int8_t *shadow, int nthreads) {
+    oa_texture slots[OA_MAX_TEXTURE_SLOTS];
+    for (uint32_t i = 0; i < sc->n_triangles; i++) if (sc->triangles[i].mat >= n_mats) return -2;
+    for (uint32_t i = 0; i < n_mats; i++) if (mats[i].tex_slot < -1 || mats[i].tex_slot >= OA_MAX_TEXTURE_SLOTS) return -2;
+    for (int k = 0; k < OA_MAX_TEXTURE_SLOTS; k++) { slots[k].rgb = tex_rgb[k]; slots[k].w = tex_w[k]; slots[k].h = tex_h[k]; }
+    oa_job j;
+    memset(&j, 0, sizeof j);
+    j.sc = sc; j.n = n; j.dir = dir; j.org = org; j.has_tc = has_texcoords; j.has_n = has_normals;
+    j.mats = mats; j.slots = slots;
     j.rgba = rgba; j.hit_id = hit_id; j.hit_t = hit_t; j.counts = counts; j.shadow = shadow; j.mode = 0;
     return run_jobs(&j, nthreads);
 }

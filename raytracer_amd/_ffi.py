@@ -158,6 +158,8 @@ def device_lib():
         L.rtamd_upload_scene.restype = ctypes.c_int
         L.rtamd_upload_texture.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint32, ctypes.c_uint32]
         L.rtamd_upload_texture.restype = ctypes.c_int
+        L.rtamd_upload_materials.argtypes = [vp, vp, ctypes.c_uint32]
+        L.rtamd_upload_materials.restype = ctypes.c_int
         for name in ("rtamd_render", "rtamd_render_device"):
             getattr(L, name).argtypes = [vp, ctypes.POINTER(FrameDesc), ctypes.POINTER(FrameOut)]
             getattr(L, name).restype = ctypes.c_int

@@ -5,8 +5,9 @@ frame writer in place of the display pass.
                    ResourceParser::parse_model / parse_material_lib (resource_parser.rs:13-109): the model's
                    material ids are in first-`usemtl` order (model.rs:89-97); material i's map_Kd image
                    becomes albedo slot i.  The fused shader has modelTextures[2] (ray_trace_and_shade.frag:21):
-                   triangles of further materials sample slot (mat_idx & 1) on the device, so more than two
-                   textured materials are reported, not silently mis-rendered.
+                   without a material table triangles of further materials sample slot (mat_idx & 1), so more
+                   than two textured materials are reported; with `shading_materials` handed to
+                   HipRayTracer.upload_materials every material has its own slot (16) and its MTL Ka/Kd/Ks/Ns.
   frame_to_rgb8 /  util/display.frag:9 writes the colour target to an 8-bit unorm back buffer: clamp to
   write_ppm /      [0,1], x255, round to nearest; frames are stored bottom row first (GL), images top row
   write_png        first.
@@ -54,8 +55,12 @@ def _read_ppm(path):
 
 
 def load_obj_scene(obj_path, texture_dirs=(), bvh_threads=1):
-    """Returns dict(model, scene, materials, textures, warnings): `scene` is ready for
-    HipRayTracer.upload_scene, textures[i] (or None) for upload_texture(i, ...) with i in {0, 1}."""
+    """Returns dict(model, scene, materials, textures, shading_materials, warnings).
+    `scene` is ready for HipRayTracer.upload_scene; textures[i] (or None) is material i's map_Kd image for
+    upload_texture(i, ...), i < 16.  Slots 0 and 1 are what the reference shader samples (modelTextures[2]);
+    `shading_materials` is the table for upload_materials (Ka / Kd / Ks / Ns of material.rs:5-16 and
+    texture slot i, or -1), with which materials 2..15 get their own textures and every material its MTL colours."""
+    from .renderer import MAX_TEXTURE_SLOTS, SHADING_MATERIAL_DTYPE
     base = os.path.dirname(os.path.abspath(obj_path))
     with open(obj_path, "r", encoding="utf-8", errors="replace") as f:
         model = host.ResourceParser.parse_model(f.read())
@@ -65,29 +70,36 @@ def load_obj_scene(obj_path, texture_dirs=(), bvh_threads=1):
         with open(os.path.join(base, lib), "r", encoding="utf-8", errors="replace") as f:
             for name, mat in host.ResourceParser.parse_material_lib(f.read()):
                 libs.setdefault(name, mat)
-    warnings, materials, textures = [], [], [None, None]
+    names = model.materials()
+    warnings, materials, textures = [], [], [None] * max(2, min(len(names), MAX_TEXTURE_SLOTS))
+    table = np.zeros(len(names), SHADING_MATERIAL_DTYPE)
     search = [base] + [os.path.abspath(d) for d in texture_dirs]
-    for i, name in enumerate(model.materials()):
+    for i, name in enumerate(names):
         mat = libs.get(name)
         if mat is None:
             warnings.append(f"material '{name}' (id {i}) is not defined in any mtllib: default material")
             mat = host.ResourceParser.parse_material_lib("newmtl _default\n")[0][1]
         materials.append((name, mat))
+        table[i] = (mat["ambient_color"], mat["diffuse_color"], mat["specular_color"], mat["specular_exp"], -1)
         tex = mat["diffuse_tex"]
         if tex is None:
             continue
-        if i >= 2:
-            warnings.append(f"material '{name}' (id {i}) has map_Kd {tex}, but the fused shader has modelTextures[2]: "
-                            f"its triangles sample slot {i & 1}")
+        if i >= MAX_TEXTURE_SLOTS:
+            warnings.append(f"material '{name}' (id {i}) has map_Kd {tex}, but there are {MAX_TEXTURE_SLOTS} texture slots: untextured")
             continue
+        if i >= 2:
+            warnings.append(f"material '{name}' (id {i}) has map_Kd {tex}: the reference shader has modelTextures[2] (its triangles "
+                            f"would sample slot {i & 1}); slot {i} is used only with upload_materials(shading_materials)")
         for d in search:
             p = os.path.join(d, tex)
             if os.path.exists(p):
                 textures[i] = load_image_rgb8(p)
+                table[i]["texture_slot"] = i
                 break
         else:
             warnings.append(f"texture {tex} of material '{name}' not found in {search}: slot {i} stays white")
-    return {"model": model, "scene": model.scene_arrays(), "materials": materials, "textures": textures, "warnings": warnings}
+    return {"model": model, "scene": model.scene_arrays(), "materials": materials, "textures": textures,
+            "shading_materials": table, "warnings": warnings}
 
 
 def frame_to_rgb8(rgba, width, height):

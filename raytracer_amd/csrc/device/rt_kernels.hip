@@ -50,6 +50,17 @@ constexpr int BLOCK = RTAMD_BLOCK;   // threads per workgroup of the traversal k
 #endif
 #define RTAMD_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(RTAMD_WAVES_PER_EU, RTAMD_WAVES_PER_EU)))
 
+// Per-material shading parameters: the MTL quantities of src/rendering/material.rs:5-16 the fused
+// shader has a use for (it hard-codes AMBIENT / DIFFUSE / SPECULAR / SPEC_POW, ray_trace_and_shade.frag:184-187).
+struct MaterialDev {
+    float ka[3], kd[3], ks[3];    // ambient_color, diffuse_color, specular_color
+    float ns;                     // specular_exp
+    uint32_t tex_slot;            // albedo texture slot (diffuse_tex); RTAMD_MAX_TEXTURE_SLOTS = the 1x1 white texel
+    uint32_t pad;
+};
+static_assert(sizeof(MaterialDev) == 48, "MaterialDev must be 48 bytes");
+struct TexSlotDev { const uint32_t *texels; int32_t w, h; };
+
 struct SceneDev {
     const WideNode *nodes;
     const TriRecord *tris;        // == (char*)nodes + tri_byte_offset (same allocation)
@@ -60,6 +71,10 @@ struct SceneDev {
     const float *texcoords;       // 2 per vertex or nullptr
     const uint32_t *tex[2];       // RGBA8 texels, row-major, first row first
     int32_t tex_w[2], tex_h[2];
+    // optional per-material shading (rtamd_upload_materials): nullptr = the
+    // shader's hard-coded constants and modelTextures[2]
+    const MaterialDev *materials;
+    const TexSlotDev *tex_slots;  // RTAMD_MAX_TEXTURE_SLOTS + 1 entries; a slot never uploaded, and the last, = the 1x1 white texel
     float root_box[6];
     uint32_t root_ref;
 };
@@ -450,6 +465,7 @@ __device__ __forceinline__ V3 sample_albedo(const uint32_t *__restrict__ tex, in
 
 // Hit branch of main (:207-229) up to the shadow traversal: computes the shading
 // normal, the two candidate colours (lit / in shadow) and the shadow ray.
+template <bool MAT = false>
 __device__ __forceinline__ void shade_primary(const SceneDev &s, const JobParams &p, const Trav &tr, V3 &col_shadow, V3 &col_lit, Ray &shadow_ray) {
     const RefTriangle tri = s.tri_idx[tr.idx];
     const float u = tr.u, v = tr.v;
@@ -484,14 +500,28 @@ __device__ __forceinline__ void shade_primary(const SceneDev &s, const JobParams
     // shadow ray (:214-217): org + dir * t + normal * 0.0001
     set_ray(shadow_ray, (r.ox + r.dx * tr.t) + nx * 0.0001f, (r.oy + r.dy * tr.t) + ny * 0.0001f, (r.oz + r.dz * tr.t) + nz * 0.0001f,
             sd.x, sd.y, sd.z);
-    const uint32_t m = tri.mat_idx & 1u;
-    V3 albedo = sample_albedo(s.tex[m], s.tex_w[m], s.tex_h[m], tcx, -tcy);
+    // AMBIENT, DIFFUSE, SPECULAR, SPEC_POW (:184-187) — or, with a material table, the triangle's
+    // material: the same expressions with Ka / Kd / Ks / Ns in the constants' places, so a table
+    // holding (.5, .8, .4, 30) reproduces the reference bit for bit
+    float ka[3] = {0.5f, 0.5f, 0.5f}, kd[3] = {0.8f, 0.8f, 0.8f}, ks[3] = {0.4f, 0.4f, 0.4f}, ns = 30.0f;
+    V3 albedo;
+    if (MAT) {
+        const MaterialDev &md = s.materials[tri.mat_idx];   // upload checked mat_idx < table size
+#pragma unroll
+        for (int k = 0; k < 3; k++) { ka[k] = md.ka[k]; kd[k] = md.kd[k]; ks[k] = md.ks[k]; }
+        ns = md.ns;
+        const TexSlotDev ts = s.tex_slots[md.tex_slot];     // "no texture" is the slot of the 1x1 white texel
+        albedo = sample_albedo(ts.texels, ts.w, ts.h, tcx, -tcy);
+    } else {
+        const uint32_t m = tri.mat_idx & 1u;
+        albedo = sample_albedo(s.tex[m], s.tex_w[m], s.tex_h[m], tcx, -tcy);
+    }
     V3 sky = skybox(nx, ny, nz);
     float ndl = clamp01(dot_zyx(nx, ny, nz, sd.x, sd.y, sd.z));
-    float spec = pow_clamp01(dot_zyx(rfx, rfy, rfz, sd.x, sd.y, sd.z), 30.0f);
-    V3 ambient{(albedo.x * sky.x) * 0.5f, (albedo.y * sky.y) * 0.5f, (albedo.z * sky.z) * 0.5f};
-    V3 diffuse{((albedo.x * 1.0f) * ndl) * 0.8f, ((albedo.y * 0.97f) * ndl) * 0.8f, ((albedo.z * 0.86f) * ndl) * 0.8f};
-    V3 specular{(1.0f * spec) * 0.4f, (0.97f * spec) * 0.4f, (0.86f * spec) * 0.4f};
+    float spec = pow_clamp01(dot_zyx(rfx, rfy, rfz, sd.x, sd.y, sd.z), ns);
+    V3 ambient{(albedo.x * sky.x) * ka[0], (albedo.y * sky.y) * ka[1], (albedo.z * sky.z) * ka[2]};
+    V3 diffuse{((albedo.x * 1.0f) * ndl) * kd[0], ((albedo.y * 0.97f) * ndl) * kd[1], ((albedo.z * 0.86f) * ndl) * kd[2]};
+    V3 specular{(1.0f * spec) * ks[0], (0.97f * spec) * ks[1], (0.86f * spec) * ks[2]};
     col_lit = V3{(ambient.x + diffuse.x) + specular.x, (ambient.y + diffuse.y) + specular.y, (ambient.z + diffuse.z) + specular.z};
     // in shadow: diffuse *= 0, specular *= 0 (:226-229)
     col_shadow = V3{(ambient.x + diffuse.x * 0.0f) + specular.x * 0.0f, (ambient.y + diffuse.y * 0.0f) + specular.y * 0.0f,
@@ -589,7 +619,7 @@ __device__ __forceinline__ uint32_t ray_pos_flag(const Ray &r) {
 // ---------------------------------------------------------------------------
 // k_persistent — production kernel
 // ---------------------------------------------------------------------------
-template <int MODE, bool COUNT>
+template <int MODE, bool COUNT, bool MAT = false>
 __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(const SceneDev s, const JobParams p) {
     __shared__ uint32_t lds_stack[LDS_STACK_ENTRIES * BLOCK];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -805,7 +835,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                 prim_t = tr.t; prim_idx = tr.idx;
                 if (tr.t < T_HIT_LIMIT) {
                     Ray sray;
-                    shade_primary(s, p, tr, col_shadow, col_lit, sray);
+                    shade_primary<MAT>(s, p, tr, col_shadow, col_lit, sray);
                     tr.ray = sray;
                     trav_begin<COUNT>(s, tr, T_PRIMARY0, st.sp_init(tid), nbox);
                     phase = PH_SHADOW | ray_pos_flag(sray);
@@ -852,7 +882,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
 // k_static — A/B baseline: one lane per pixel / ray, one 64-lane item per wave,
 // no persistence, no re-fill.  Same device functions, same results.
 // ---------------------------------------------------------------------------
-template <int MODE, bool COUNT>
+template <int MODE, bool COUNT, bool MAT = false>
 __global__ void __launch_bounds__(BLOCK) k_static(const SceneDev s, const JobParams p) {
     __shared__ uint32_t lds_stack[LDS_STACK_ENTRIES * BLOCK];
 #ifdef RTAMD_EXP_PAD_LDS   // occupancy experiment only: waste LDS to cap resident blocks
@@ -903,7 +933,7 @@ __global__ void __launch_bounds__(BLOCK) k_static(const SceneDev s, const JobPar
     if (tr.t < T_HIT_LIMIT) {
         V3 col_shadow, col_lit;
         Ray sray;
-        shade_primary(s, p, tr, col_shadow, col_lit, sray);
+        shade_primary<MAT>(s, p, tr, col_shadow, col_lit, sray);
         tr.ray = sray;
         trav_begin<COUNT>(s, tr, T_PRIMARY0, st.sp_init(tid), nbox);
         trav_run<COUNT>(s, tr, st, tid, nbox, ntri, p.shadow_anyhit != 0);

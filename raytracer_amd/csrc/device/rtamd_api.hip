@@ -59,15 +59,19 @@ struct rtamd_context {
     std::string err;
     int variant = 0;
     int num_cu = 0;
-    int persistent_blocks_per_cu[4] = {0, 0, 0, 0};  // [mode*2 + count]
+    int persistent_blocks_per_cu[6] = {0, 0, 0, 0, 0, 0};  // [mode*2 + count]; [4 + count]: fused with a material table
     // scene
     bool has_scene = false;
     DevBuf nodes, tris, big, tri_idx, normals, texcoords;
-    DevBuf tex[2];
+    DevBuf tex[RTAMD_MAX_TEXTURE_SLOTS];
     DevBuf noise;
     int32_t noise_w = 0, noise_h = 0;
-    int32_t tex_w[2] = {1, 1}, tex_h[2] = {1, 1};
+    int32_t tex_w[RTAMD_MAX_TEXTURE_SLOTS] = {}, tex_h[RTAMD_MAX_TEXTURE_SLOTS] = {};   // valid where tex[k].p is set
     DevBuf white;
+    // optional per-material shading (rtamd_upload_materials)
+    DevBuf materials, tex_slots;
+    uint32_t n_materials = 0;
+    uint32_t scene_max_mat = 0;       // largest mat_idx of the uploaded scene's triangles
     bool adaptive_order = false;
     DevBuf ipv;  // 16 floats for k_generate_rays
 #ifdef RTAMD_EXP_STAMPS
@@ -222,6 +226,7 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
 #endif
     hipStream_t st = ctx->stream;
     const SceneDev &s = ctx->sdev;
+    const bool mat = mode == MODE_FUSED && s.materials != nullptr;   // per-material shading: its own instantiation
     // (Letting the last wave of a launch zero the counters instead — one exit atomic per wave — was measured
     // equal for the fused shader and 5 % slower for ray_trace launches, whose waves all leave at once.)
     if (ctx->variant == 0) {
@@ -243,13 +248,16 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     sl->timed = ctx->launch_timing;
     if (sl->timed) HIP_TRY(ctx, hipEventRecord(sl->ev_start, st));
     if (ctx->variant == 0) {
-        int per_cu = ctx->persistent_blocks_per_cu[mode * 2 + (count ? 1 : 0)];
+        int per_cu = ctx->persistent_blocks_per_cu[(mat ? 4 : mode * 2) + (count ? 1 : 0)];
         if (ctx->max_blocks_per_cu && (int)ctx->max_blocks_per_cu < per_cu) per_cu = (int)ctx->max_blocks_per_cu;
         uint32_t grid = (uint32_t)(ctx->num_cu * per_cu);
         uint32_t need = (p.n_items + (BLOCK / 64) - 1) / (BLOCK / 64);
         if (grid > need) grid = need;
         if (grid < 1) grid = 1;
-        if (mode == MODE_FUSED) {
+        if (mode == MODE_FUSED && mat) {
+            if (count) hipLaunchKernelGGL((k_persistent<MODE_FUSED, true, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
+            else hipLaunchKernelGGL((k_persistent<MODE_FUSED, false, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
+        } else if (mode == MODE_FUSED) {
             if (count) hipLaunchKernelGGL((k_persistent<MODE_FUSED, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
             else hipLaunchKernelGGL((k_persistent<MODE_FUSED, false>), dim3(grid), dim3(BLOCK), 0, st, s, p);
         } else {
@@ -258,7 +266,10 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
         }
     } else {
         uint32_t grid = (p.n_items + (BLOCK / 64) - 1) / (BLOCK / 64);
-        if (mode == MODE_FUSED) {
+        if (mode == MODE_FUSED && mat) {
+            if (count) hipLaunchKernelGGL((k_static<MODE_FUSED, true, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
+            else hipLaunchKernelGGL((k_static<MODE_FUSED, false, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
+        } else if (mode == MODE_FUSED) {
             if (count) hipLaunchKernelGGL((k_static<MODE_FUSED, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
             else hipLaunchKernelGGL((k_static<MODE_FUSED, false>), dim3(grid), dim3(BLOCK), 0, st, s, p);
         } else {
@@ -343,9 +354,11 @@ int rtamd_context_create(int device_ordinal, rtamd_context **out_ctx) {
     if ((rc = query_blocks(ctx, k_persistent<MODE_FUSED, true>, &ctx->persistent_blocks_per_cu[1]))) return bail(rc);
     if ((rc = query_blocks(ctx, k_persistent<MODE_TRACE, false>, &ctx->persistent_blocks_per_cu[2]))) return bail(rc);
     if ((rc = query_blocks(ctx, k_persistent<MODE_TRACE, true>, &ctx->persistent_blocks_per_cu[3]))) return bail(rc);
+    if ((rc = query_blocks(ctx, k_persistent<MODE_FUSED, false, true>, &ctx->persistent_blocks_per_cu[4]))) return bail(rc);
+    if ((rc = query_blocks(ctx, k_persistent<MODE_FUSED, true, true>, &ctx->persistent_blocks_per_cu[5]))) return bail(rc);
     {
         int max_per_cu = 1;
-        for (int k = 0; k < 4; k++) if (ctx->persistent_blocks_per_cu[k] > max_per_cu) max_per_cu = ctx->persistent_blocks_per_cu[k];
+        for (int k = 0; k < 6; k++) if (ctx->persistent_blocks_per_cu[k] > max_per_cu) max_per_cu = ctx->persistent_blocks_per_cu[k];
         size_t waves = (size_t)ctx->num_cu * max_per_cu * (BLOCK / 64);
         ctx->spill_bytes = waves * SPILL_STACK_ENTRIES * 64 * sizeof(uint32_t);
     }
@@ -369,7 +382,7 @@ void rtamd_context_destroy(rtamd_context *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();   // launches may be in flight on several (caller-owned) streams
     ctx->nodes.release(); ctx->tris.release(); ctx->big.release(); ctx->tri_idx.release();
-    ctx->normals.release(); ctx->texcoords.release(); ctx->tex[0].release(); ctx->tex[1].release(); ctx->noise.release();
+    ctx->normals.release(); ctx->texcoords.release(); for (auto &t : ctx->tex) t.release(); ctx->materials.release(); ctx->tex_slots.release(); ctx->noise.release();
     ctx->white.release(); ctx->ipv.release();
     for (auto &sl : ctx->slots) {
         sl.queues.release(); sl.spill.release(); sl.item_cost.release(); sl.item_order.release();
@@ -464,9 +477,12 @@ int rtamd_upload_scene(rtamd_context *ctx, const rtamd_scene_desc *sc) {
     const RefTriangle *tris = (const RefTriangle *)sc->triangles;
     const uint32_t n_nodes = sc->node_count, n_tris = sc->triangle_count, n_verts = sc->vertex_count;
     try {
-        for (uint32_t i = 0; i < n_tris; i++)
+        uint32_t max_mat = 0;
+        for (uint32_t i = 0; i < n_tris; i++) {
             if (tris[i].p0 >= n_verts || tris[i].p1 >= n_verts || tris[i].p2 >= n_verts)
                 return fail(ctx, RTAMD_ERR_MALFORMED_SCENE, "triangle %u references a vertex >= %u", i, n_verts);
+            if (tris[i].mat_idx > max_mat) max_mat = tris[i].mat_idx;
+        }
 
         // Walk the tree from the root: validates indices, rejects shared / cyclic
         // nodes, measures depth, and marks the reachable inner nodes.
@@ -543,6 +559,10 @@ int rtamd_upload_scene(rtamd_context *ctx, const rtamd_scene_desc *sc) {
         const size_t node_bytes = (wide.size() * sizeof(WideNode) + 127) & ~(size_t)127;
         const size_t tri_bytes = recs.size() * sizeof(TriRecord);
         if (node_bytes + tri_bytes > 0xFFFFFFF0ull) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "scene geometry exceeds the 4 GiB device layout limit");
+        // from here on the previous scene's buffers are replaced: a failure leaves the context without a scene
+        ctx->has_scene = false;
+        ctx->sdev.materials = nullptr; ctx->n_materials = 0;   // a material table belongs to the scene it was checked against
+        ctx->scene_max_mat = max_mat;
         if ((rc = dev_alloc(ctx, ctx->nodes, node_bytes + tri_bytes))) return rc;
         HIP_TRY(ctx, hipMemcpy(ctx->nodes.p, wide.data(), wide.size() * sizeof(WideNode), hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy((char *)ctx->nodes.p + node_bytes, recs.data(), tri_bytes, hipMemcpyHostToDevice));
@@ -605,14 +625,70 @@ int upload_rgb8(rtamd_context *ctx, DevBuf &dst, const uint8_t *rgb8, uint32_t w
 }
 }  // namespace
 
+namespace {
+// The slot table the material path samples through: RTAMD_MAX_TEXTURE_SLOTS entries + the white texel.
+int refresh_tex_slots(rtamd_context *ctx) {
+    TexSlotDev table[RTAMD_MAX_TEXTURE_SLOTS + 1];
+    for (int k = 0; k <= RTAMD_MAX_TEXTURE_SLOTS; k++) {
+        const bool have = k < RTAMD_MAX_TEXTURE_SLOTS && ctx->tex[k].p;
+        table[k].texels = (const uint32_t *)(have ? ctx->tex[k].p : ctx->white.p);
+        table[k].w = have ? ctx->tex_w[k] : 1;
+        table[k].h = have ? ctx->tex_h[k] : 1;
+    }
+    HIP_TRY(ctx, hipDeviceSynchronize());   // a frame in flight may still read the old table
+    if (!ctx->tex_slots.p) { int rc = dev_alloc(ctx, ctx->tex_slots, sizeof table); if (rc) return rc; }
+    HIP_TRY(ctx, hipMemcpy(ctx->tex_slots.p, table, sizeof table, hipMemcpyHostToDevice));
+    ctx->sdev.tex_slots = (const TexSlotDev *)ctx->tex_slots.p;
+    return RTAMD_OK;
+}
+}  // namespace
+
 int rtamd_upload_texture(rtamd_context *ctx, uint32_t slot, const uint8_t *rgb8, uint32_t width, uint32_t height) {
     if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
-    if (slot > 1) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "texture slot %u: the shader has modelTextures[2]", slot);
+    if (slot >= RTAMD_MAX_TEXTURE_SLOTS) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "texture slot %u: slots are 0..%d (the shader's modelTextures[2] are slots 0 and 1)", slot, RTAMD_MAX_TEXTURE_SLOTS - 1);
     int rc = upload_rgb8(ctx, ctx->tex[slot], rgb8, width, height);
     if (rc) return rc;
     ctx->tex_w[slot] = (int32_t)width; ctx->tex_h[slot] = (int32_t)height;
-    ctx->sdev.tex[slot] = (const uint32_t *)ctx->tex[slot].p;
-    ctx->sdev.tex_w[slot] = (int32_t)width; ctx->sdev.tex_h[slot] = (int32_t)height;
+    if (slot < 2) {
+        ctx->sdev.tex[slot] = (const uint32_t *)ctx->tex[slot].p;
+        ctx->sdev.tex_w[slot] = (int32_t)width; ctx->sdev.tex_h[slot] = (int32_t)height;
+    }
+    if (ctx->sdev.materials) return refresh_tex_slots(ctx);
+    return RTAMD_OK;
+}
+
+int rtamd_upload_materials(rtamd_context *ctx, const rtamd_shading_material *materials, uint32_t count) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (!ctx->has_scene) return fail(ctx, RTAMD_ERR_NO_SCENE, "no scene uploaded (the table is checked against the scene's material indices)");
+    int rc = ensure_ctx_device(ctx);
+    if (rc) return rc;
+    if (count == 0) {   // back to the shader's constants
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        ctx->sdev.materials = nullptr; ctx->n_materials = 0;
+        return RTAMD_OK;
+    }
+    if (!materials) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "materials is NULL");
+    if (count <= ctx->scene_max_mat) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "%u materials, but the scene's triangles use material index %u", count, ctx->scene_max_mat);
+    try {
+        std::vector<MaterialDev> table(count);
+        for (uint32_t i = 0; i < count; i++) {
+            const rtamd_shading_material &m = materials[i];
+            if (m.texture_slot < -1 || m.texture_slot >= RTAMD_MAX_TEXTURE_SLOTS)
+                return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "material %u: texture slot %d is not -1..%d", i, m.texture_slot, RTAMD_MAX_TEXTURE_SLOTS - 1);
+            MaterialDev &d = table[i];
+            for (int k = 0; k < 3; k++) { d.ka[k] = m.ambient_color[k]; d.kd[k] = m.diffuse_color[k]; d.ks[k] = m.specular_color[k]; }
+            d.ns = m.specular_exp;
+            d.tex_slot = m.texture_slot < 0 ? (uint32_t)RTAMD_MAX_TEXTURE_SLOTS : (uint32_t)m.texture_slot;
+            d.pad = 0;
+        }
+        HIP_TRY(ctx, hipDeviceSynchronize());   // a frame in flight may still read the old table
+        if ((rc = dev_upload(ctx, ctx->materials, table.data(), table.size() * sizeof(MaterialDev)))) { ctx->sdev.materials = nullptr; ctx->n_materials = 0; return rc; }
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, RTAMD_ERR_OUT_OF_MEMORY, "out of host memory");
+    }
+    if ((rc = refresh_tex_slots(ctx))) { ctx->sdev.materials = nullptr; ctx->n_materials = 0; return rc; }
+    ctx->sdev.materials = (const MaterialDev *)ctx->materials.p;
+    ctx->n_materials = count;
     return RTAMD_OK;
 }
 

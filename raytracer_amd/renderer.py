@@ -16,6 +16,15 @@ from .host import FAR, NEAR
 NO_HIT = 0xFFFFFFFF
 TILE_DIM = 32
 TILE_PIXELS = TILE_DIM * TILE_DIM
+MAX_TEXTURE_SLOTS = 16
+# rtamd_shading_material (include/rtamd.h): Ka, Kd, Ks, Ns, albedo texture slot (-1 = none)
+SHADING_MATERIAL_DTYPE = np.dtype([("ambient_color", "<f4", (3,)), ("diffuse_color", "<f4", (3,)), ("specular_color", "<f4", (3,)),
+                                   ("specular_exp", "<f4"), ("texture_slot", "<i4")])
+assert SHADING_MATERIAL_DTYPE.itemsize == 44
+# the constants of ray_trace_and_shade.frag:184-187 as a table entry
+def reference_material(texture_slot):
+    return ((0.5, 0.5, 0.5), (0.8, 0.8, 0.8), (0.4, 0.4, 0.4), 30.0, texture_slot)
+
 
 
 class RtamdError(RuntimeError):
@@ -101,6 +110,17 @@ class HipRayTracer:
         if t.ndim != 3 or t.shape[2] != 3:
             raise ValueError("texture must be (h, w, 3) uint8")
         self._check(self._lib.rtamd_upload_texture(self._h, int(slot), ctypes.c_void_p(t.ctypes.data), t.shape[1], t.shape[0]))
+
+    def upload_materials(self, materials):
+        """Per-material shading table (rtamd_upload_materials): an (n,) array of SHADING_MATERIAL_DTYPE, or a
+        sequence of (ambient_color, diffuse_color, specular_color, specular_exp, texture_slot) tuples;
+        None or an empty sequence restores the shader's constants."""
+        if materials is None or len(materials) == 0:
+            self._check(self._lib.rtamd_upload_materials(self._h, None, 0))
+            return
+        m = np.ascontiguousarray(np.array([tuple(x) for x in materials], dtype=SHADING_MATERIAL_DTYPE)
+                                 if not isinstance(materials, np.ndarray) else materials, dtype=SHADING_MATERIAL_DTYPE)
+        self._check(self._lib.rtamd_upload_materials(self._h, ctypes.c_void_p(m.ctypes.data), len(m)))
 
     # ---- fused render -----------------------------------------------------
     def _frame_desc(self, width, height, dir_ptr, org_ptr, camera, has_tex_coords, has_normals, tile_rank, tile_world):

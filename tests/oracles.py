@@ -127,6 +127,34 @@ class OracleA:
                               shadow.ctypes.data, nthreads)
         return {"rgba": rgba, "hit_id": hit_id, "hit_t": hit_t, "counts": counts, "shadow": shadow, "overflow": rc != 0}
 
+    def render_materials(self, scene, dir, org, has_tex_coords, has_normals, materials, textures, nthreads=1):
+        """The fused shader with a material table: `materials` an (n,) array of the renderer's
+        SHADING_MATERIAL_DTYPE, `textures` a dict slot -> (h, w, 3) uint8.  Same outputs as render()."""
+        from raytracer_amd.renderer import MAX_TEXTURE_SLOTS, SHADING_MATERIAL_DTYPE
+        keep = []
+        sc = _scene_struct(scene, keep)
+        d = np.ascontiguousarray(dir, dtype=np.float32).reshape(-1, 3)
+        o = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
+        n = len(d)
+        m = np.ascontiguousarray(materials, dtype=SHADING_MATERIAL_DTYPE)
+        tex = {int(k): np.ascontiguousarray(v, dtype=np.uint8) for k, v in textures.items()}
+        ptrs = (ctypes.c_void_p * MAX_TEXTURE_SLOTS)(*[tex[k].ctypes.data if k in tex else None for k in range(MAX_TEXTURE_SLOTS)])
+        ws = (ctypes.c_int * MAX_TEXTURE_SLOTS)(*[tex[k].shape[1] if k in tex else 0 for k in range(MAX_TEXTURE_SLOTS)])
+        hs = (ctypes.c_int * MAX_TEXTURE_SLOTS)(*[tex[k].shape[0] if k in tex else 0 for k in range(MAX_TEXTURE_SLOTS)])
+        rgba = np.zeros((n, 4), np.float32)
+        hit_id = np.zeros(n, np.uint32)
+        hit_t = np.zeros(n, np.float32)
+        counts = np.zeros((n, 2), np.uint32)
+        shadow = np.zeros(n, np.int8)
+        self.L.oa_render_materials.restype = ctypes.c_int
+        rc = self.L.oa_render_materials(ctypes.byref(sc), ctypes.c_uint64(n), ctypes.c_void_p(d.ctypes.data), ctypes.c_void_p(o.ctypes.data),
+                                        int(has_tex_coords), int(has_normals), ctypes.c_void_p(m.ctypes.data), ctypes.c_uint32(len(m)), ptrs, ws, hs,
+                                        ctypes.c_void_p(rgba.ctypes.data), ctypes.c_void_p(hit_id.ctypes.data), ctypes.c_void_p(hit_t.ctypes.data),
+                                        ctypes.c_void_p(counts.ctypes.data), ctypes.c_void_p(shadow.ctypes.data), int(nthreads))
+        if rc == -2:
+            raise ValueError("material table does not cover the scene, or a texture slot is out of range")
+        return {"rgba": rgba, "hit_id": hit_id, "hit_t": hit_t, "counts": counts, "shadow": shadow, "overflow": rc != 0}
+
     def trace(self, scene, org, dir, nthreads=1):
         keep = []
         sc = _scene_struct(scene, keep)

@@ -94,3 +94,8 @@ def test_load_obj_scene_with_materials_and_textures(tmp_path):
     assert r["scene"]["tex_coords"] is not None and len(r["scene"]["nodes"]) >= 2
     w = "\n".join(r["warnings"])
     assert "third" in w and "modelTextures[2]" in w and "nowhere" in w and "not defined" in w
+    # the table for upload_materials: MTL defaults (Ka 0.3, Kd 1, Ks 1, Ns 10, material.rs:26-31), map_Kd -> slot = material id
+    t = r["shading_materials"]
+    assert len(t) == 4 and t["texture_slot"].tolist() == [0, 1, -1, -1]      # c.png does not exist, `nowhere` has no map_Kd
+    assert np.allclose(t["ambient_color"], 0.3) and np.all(t["diffuse_color"] == 1) and np.all(t["specular_exp"] == 10)
+    assert len(r["textures"]) == 4 and r["textures"][2] is None

@@ -58,7 +58,7 @@ def test_errors():
             t.render(8, 8, dir=np.ones((64, 3), np.float32), org=np.zeros((64, 3), np.float32), has_normals=True)
         assert e.value.code == -1                                   # scene has no normals
         with pytest.raises(RtamdError):
-            t.upload_texture(2, np.zeros((2, 2, 3), np.uint8))
+            t.upload_texture(16, np.zeros((2, 2, 3), np.uint8))         # slots are 0..15
         with pytest.raises(RtamdError):
             t.set_option("no_such_option", 1)
         assert t.trace(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32)).shape == (0, 4)
