@@ -195,6 +195,9 @@ def main():
         if world > 1 and F > 1 and k >= F:
             rs.wait_event(consumed[f])          # rgba[f] is free again once frame k-F has been gathered
         tracer.set_stream(rs.cuda_stream)
+        # launch durations for the roofline: every launch on one GPU; with N > 1 the host has ~40 us per step
+        # for everything (render call, gather, assembly), so only every 8th launch carries the two extra events
+        timed = timed and (world == 1 or k % 8 == 0)
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(rs)
