@@ -305,15 +305,10 @@ int rtamd_set_kernel_variant(rtamd_context *ctx, int variant);
  *  "num_queues" 1..32   work-queue counters (8 = one per XCD);
  *  "queue_stride" 1..4096  u32 words between the counters (default 64 = 256 B, one memory
  *                       channel each);
- *  "chunk" 1..64        schedule positions a wave takes per atomic (default 1);
  *  "max_blocks_per_cu" 0..64  cap on resident workgroups per CU (0 = all that fit, 8); 6 is 2.5-4 % faster on
  *                       incoherent rays, 8 on coherent ones;
  *  "queue_block" 1..65536  consecutive schedule positions (work items) a queue owns per turn, i.e. the size of
  *                       the screen region the waves of one XCD share (default 256 for frames, 1 for ray lists);
- *  "prio_thresh" >= 0   0 = off (default); else a wave raises its issue priority once its
- *                       current item has cost this many loop-iteration units (again at x3, x7);
- *  "adaptive_order" 0/1 schedule a frame's items by the cost counted for them in the previous
- *                       launch of the same size, longest first (default 0: measured slower);
  *  "launch_timing" 0/1  record a start event in front of every launch (default 1); 0 saves one
  *                        stream operation per launch, rtamd_last_kernel_ms then reports an error.
  *  "shadow_anyhit" 0/1  fused shader only (default 1): a shadow ray stops at the first leaf that

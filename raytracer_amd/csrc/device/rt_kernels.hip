@@ -111,10 +111,6 @@ struct JobParams {
     uint32_t dyn_auto;            // 1: pick the lane re-fill threshold from stats_prev (coherent: 1, incoherent: dyn_incoherent)
     uint32_t dyn_incoherent;
     uint32_t queue_block;         // consecutive schedule positions a queue owns per turn
-    uint32_t chunk;               // schedule positions taken per atomic
-    uint32_t prio_thresh;         // 0 = off; else a wave raises its issue priority when its item has cost this much work (x2, x4)
-    const uint32_t *item_order;   // schedule position -> item, or nullptr (identity)
-    uint32_t *item_cost;          // per item: weighted wave-level loop iterations spent on it this frame (feeds the next schedule), or nullptr
     uint32_t *spill;              // k_persistent: [wave slot][SPILL_STACK_ENTRIES][64] stack overflow area
 #ifdef RTAMD_EXP_STAMPS
     unsigned long long *stamps;   // diagnostic build only: per wave {start, end, items, xcc} in 100 MHz ticks
@@ -565,11 +561,11 @@ __device__ __forceinline__ PixelRef item_pixel(const JobParams &p, uint32_t item
 }
 
 // ---------------------------------------------------------------------------
-// queues: n_queues counters (64 bytes apart) over ONE schedule (item_order: items
-// sorted by the cost the previous frame measured for them, longest first — LPT
-// scheduling; identity on the first frame).  A wave starts on the counter of its
-// XCD and steals from the others when that one is exhausted; which wave renders
-// which item never changes a result bit.
+// queues: n_queues counters (queue_stride words apart) over ONE schedule, the items in
+// their natural (tile) order.  A wave starts on the counter of its XCD and steals from the
+// others when that one is exhausted; which wave renders which item never changes a result
+// bit.  (Ordering the items by the cost the previous frame counted for them — LPT or
+// heavy-first — was measured slower and removed)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t xcc_id() {
     uint32_t v;
@@ -592,7 +588,7 @@ __device__ __forceinline__ uint32_t fetch_item(const JobParams &p, uint32_t home
             const uint32_t pos = p.queue_block == 1u ? q.v_next * p.n_queues + q.k
                                                      : ((q.v_next / p.queue_block) * p.n_queues + q.k) * p.queue_block + q.v_next % p.queue_block;
             q.v_next++;
-            if (pos < p.n_items) return p.item_order ? p.item_order[pos] : pos;
+            if (pos < p.n_items) return pos;
             q.v_next = q.v_end;   // this queue is exhausted
             q.tried++;
         }
@@ -600,9 +596,9 @@ __device__ __forceinline__ uint32_t fetch_item(const JobParams &p, uint32_t home
         uint32_t k = home + q.tried;
         if (k >= p.n_queues) k -= p.n_queues;
         uint32_t v = 0;
-        if (lane == 0) v = atomicAdd(&p.queues[k * p.queue_stride], p.chunk);
+        if (lane == 0) v = atomicAdd(&p.queues[k * p.queue_stride], 1u);   // one position per atomic: 2 / 4 were 6 % / 50 % slower
         v = __builtin_amdgcn_readfirstlane(v);
-        q.k = k; q.v_next = v; q.v_end = v + p.chunk;
+        q.k = k; q.v_next = v; q.v_end = v + 1u;
     }
 }
 
@@ -634,9 +630,6 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
     // home queue: the wave's XCD, and with more than 8 queues one of that XCD's nq/8 counters
     const uint32_t home = p.n_queues > 8 ? (xcc_id() + 8u * ((blockIdx.x >> 3) % (p.n_queues >> 3))) % p.n_queues
                                          : (p.n_queues > 1 ? xcc_id() % p.n_queues : 0u);
-    uint32_t item_work = 0;   // wave-level loop iterations since pool_item was fetched (contention-free cost)
-    bool item_live = false;
-    uint32_t prio_level = 0, prio_next = p.prio_thresh ? p.prio_thresh : 0xFFFFFFFFu;
 #ifdef RTAMD_EXP_STAMPS
     const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long stamp_items = 0, stamp_last = stamp_t0, stamp_worst = 0, stamp_worst_item = 0;
@@ -679,10 +672,6 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
         while (idle != 0ull && !drained) {
             if (pool_next >= 64u) {
                 uint32_t item = fetch_item(p, home, qc, lane);
-                if (p.item_cost) {   // wave-level iterations since the previous fetch = what that item cost
-                    if (item_live && lane == 0) p.item_cost[pool_item] = item_work;
-                    item_work = 0; item_live = true;
-                }
 #ifdef RTAMD_EXP_STAMPS
                 {   // with dyn_thresh == 1 a fetch happens only when the previous item is completely done
                     unsigned long long now = __builtin_amdgcn_s_memrealtime();
@@ -701,9 +690,6 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
 #endif
                 if (item == 0xFFFFFFFFu) { drained = true; break; }
                 pool_item = item; pool_next = 0;
-                if (prio_level) { __builtin_amdgcn_s_setprio(0); prio_level = 0; }
-                item_work = 0;
-                prio_next = p.prio_thresh ? p.prio_thresh : 0xFFFFFFFFu;
             }
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             const uint32_t avail = 64u - pool_next;
@@ -786,7 +772,6 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                     stat_uniform += trav_inner_step<COUNT, OCT>(s, tr, st, tid, in, m_in, nbox) ? 1u : 0u;
                     stat_inner += 1u;
                     stat_lanes += (uint32_t)__popcll(m_in);
-                    item_work += 2;
                 }
             };
             if (!oct_wave) inner_loop(std::integral_constant<int, -1>{});
@@ -799,14 +784,6 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                 case 5: inner_loop(std::integral_constant<int, 5>{}); break;
                 case 6: inner_loop(std::integral_constant<int, 6>{}); break;
                 default: inner_loop(std::integral_constant<int, 7>{}); break;
-            }
-            item_work += 3;
-            if (item_work >= prio_next) {   // the longer a wave has held its item, the sooner the SIMD issues it
-                prio_level++;
-                if (prio_level == 1) __builtin_amdgcn_s_setprio(1);
-                else if (prio_level == 2) __builtin_amdgcn_s_setprio(2);
-                else __builtin_amdgcn_s_setprio(3);
-                prio_next = prio_level >= 3 ? 0xFFFFFFFFu : prio_next + (p.prio_thresh << prio_level);
             }
             {
                 const bool lf = (int32_t)tr.cur < 0;
@@ -999,49 +976,6 @@ __global__ void __launch_bounds__(256) k_surface_from_hits(const SceneDev s, uin
     }
     position[3 * i] = px; position[3 * i + 1] = py; position[3 * i + 2] = pz;
     reinterpret_cast<float4 *>(normal_mat)[i] = nm;
-}
-
-// Next frame's schedule (adaptive_order).  Items whose counted cost is at least
-// `heavy_num/4` times the mean start first, heaviest first (64 linear classes, arbitrary
-// inside a class); all others follow in their natural (tile) order, which keeps the cache
-// behaviour of the fixed schedule.  heavy_num = 0 sorts everything (plain LPT).
-// One workgroup: n is a few 10^4..10^5 and the kernel runs once per frame behind the render kernel.
-__global__ void __launch_bounds__(1024) k_reorder(const uint32_t *__restrict__ cost, uint32_t n, uint32_t heavy_num, uint32_t *__restrict__ order) {
-    __shared__ uint32_t s_max, s_hist[64], s_base[64], s_scan[1024];
-    __shared__ unsigned long long s_sum;
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) { s_max = 1; s_sum = 0; }
-    if (tid < 64) s_hist[tid] = 0;
-    __syncthreads();
-    uint32_t m = 0;
-    unsigned long long sum = 0;
-    for (uint32_t i = tid; i < n; i += 1024) { m = max(m, cost[i]); sum += cost[i]; }
-    atomicMax(&s_max, m);
-    atomicAdd(&s_sum, sum);
-    __syncthreads();
-    const uint32_t quantum = s_max / 64u + 1u;
-    const uint32_t heavy = (uint32_t)min((unsigned long long)0xFFFFFFFFu, s_sum * heavy_num / (4ull * max(n, 1u)));
-    // natural-order part: thread t owns the contiguous chunk [t*per, (t+1)*per)
-    const uint32_t per = (n + 1023u) / 1024u;
-    const uint32_t lo = min(n, tid * per), hi = min(n, lo + per);
-    uint32_t light = 0;
-    for (uint32_t i = lo; i < hi; i++) {
-        if (cost[i] >= heavy) atomicAdd(&s_hist[min(63u, cost[i] / quantum)], 1u);
-        else light++;
-    }
-    s_scan[tid] = light;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t acc = 0;
-        for (int b = 63; b >= 0; b--) { s_base[b] = acc; acc += s_hist[b]; }
-        for (uint32_t t = 0; t < 1024; t++) { uint32_t c = s_scan[t]; s_scan[t] = acc; acc += c; }
-    }
-    __syncthreads();
-    uint32_t pos = s_scan[tid];
-    for (uint32_t i = lo; i < hi; i++) {
-        if (cost[i] >= heavy) order[atomicAdd(&s_base[min(63u, cost[i] / quantum)], 1u)] = i;
-        else order[pos++] = i;
-    }
 }
 
 // ---------------------------------------------------------------------------

@@ -47,9 +47,6 @@ struct rtamd_context {
         uint64_t launches = 0;              // persistent-kernel launches on this stream since the statistics layout last changed
         int stats_mode = -1;                // mode of the launch that wrote the latest statistics
         uint32_t *stats_last = nullptr;     // where that launch put them
-        // adaptive_order: per-item cost counted by launch f orders the items of launch f+1
-        DevBuf item_cost, item_order;
-        uint32_t order_items[2] = {0, 0};   // n_items the schedule of mode [fused, trace] is valid for (0 = none yet)
     };
     static constexpr int MAX_SLOTS = 8;
     Slot slots[MAX_SLOTS];
@@ -72,7 +69,6 @@ struct rtamd_context {
     DevBuf materials, tex_slots;
     uint32_t n_materials = 0;
     uint32_t scene_max_mat = 0;       // largest mat_idx of the uploaded scene's triangles
-    bool adaptive_order = false;
     DevBuf ipv;  // 16 floats for k_generate_rays
 #ifdef RTAMD_EXP_STAMPS
     DevBuf stamps;
@@ -86,11 +82,9 @@ struct rtamd_context {
     bool dyn_auto = true;
     uint32_t dyn_incoherent = 32;
     uint32_t leaf_thresh = 8;
-    uint32_t prio_thresh = 0;
     bool shadow_anyhit = true;
     bool launch_timing = true;        // record a start event per launch (rtamd_last_kernel_ms); the stop event is always recorded
-    uint32_t heavy_num = 8;   // adaptive_order: items costing >= heavy_num/4 x mean go first
-    uint32_t queue_stride = 64, chunk = 1;
+    uint32_t queue_stride = 64;
     uint32_t max_blocks_per_cu = 0;   // 0 = as many as fit (8 workgroups = 8 waves per SIMD)
     uint32_t queue_block_fused = 256, queue_block_trace = 1;   // measured: 256-item regions per XCD turn help camera frames 1.5 %, not ray lists
     uint32_t n_queues = 8;
@@ -183,7 +177,6 @@ int acquire_slot(rtamd_context *ctx, rtamd_context::Slot **out) {
     if (!sl->spill.p && (rc = dev_alloc(ctx, sl->spill, ctx->spill_bytes))) return rc;
     sl->launches = 0; sl->stats_last = nullptr;
     sl->key = ctx->stream; sl->bound = true; sl->ev_valid = false;
-    sl->order_items[0] = sl->order_items[1] = 0;
     sl->last_use = ++ctx->use_clock;
     *out = sl;
     return RTAMD_OK;
@@ -203,24 +196,9 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     p.dyn_incoherent = ctx->dyn_incoherent;
     p.stats_prev = nullptr; p.stats_cur = nullptr;
     p.leaf_thresh = ctx->leaf_thresh;
-    p.prio_thresh = ctx->prio_thresh;
     p.shadow_anyhit = ctx->shadow_anyhit ? 1u : 0u;
-    p.queue_stride = ctx->queue_stride; p.chunk = ctx->chunk; p.queue_block = mode == MODE_FUSED ? ctx->queue_block_fused : ctx->queue_block_trace;
+    p.queue_stride = ctx->queue_stride; p.queue_block = mode == MODE_FUSED ? ctx->queue_block_fused : ctx->queue_block_trace;
     p.spill = (uint32_t *)sl->spill.p;
-    p.item_cost = nullptr; p.item_order = nullptr;
-    if (ctx->variant == 0 && ctx->adaptive_order) {
-        // one cost / order array pair per mode, sized for the largest launch seen so far
-        const size_t need = (size_t)p.n_items * sizeof(uint32_t);
-        if (sl->item_cost.bytes < 2 * need) {
-            int rc;
-            if (sl->ev_valid) HIP_TRY(ctx, hipEventSynchronize(sl->ev_stop));   // the old arrays may still be in use
-            if ((rc = dev_alloc(ctx, sl->item_cost, 2 * need)) || (rc = dev_alloc(ctx, sl->item_order, 2 * need))) return rc;
-            sl->order_items[0] = sl->order_items[1] = 0;
-        }
-        const size_t half = sl->item_cost.bytes / 2 / sizeof(uint32_t);
-        p.item_cost = (uint32_t *)sl->item_cost.p + (size_t)mode * half;
-        if (sl->order_items[mode] == p.n_items) p.item_order = (const uint32_t *)sl->item_order.p + (size_t)mode * half;
-    }
 #ifdef RTAMD_EXP_STAMPS
     p.stamps = (unsigned long long *)ctx->stamps.p;
 #endif
@@ -280,13 +258,6 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(sl->ev_stop, st));
     sl->ev_valid = true;
-    if (p.item_cost) {
-        const size_t half = sl->item_cost.bytes / 2 / sizeof(uint32_t);
-        hipLaunchKernelGGL(k_reorder, dim3(1), dim3(1024), 0, st, (const uint32_t *)p.item_cost, p.n_items, ctx->heavy_num,
-                           (uint32_t *)sl->item_order.p + (size_t)mode * half);
-        HIP_TRY(ctx, hipGetLastError());
-        sl->order_items[mode] = p.n_items;
-    }
     return RTAMD_OK;
 }
 
@@ -385,7 +356,7 @@ void rtamd_context_destroy(rtamd_context *ctx) {
     ctx->normals.release(); ctx->texcoords.release(); for (auto &t : ctx->tex) t.release(); ctx->materials.release(); ctx->tex_slots.release(); ctx->noise.release();
     ctx->white.release(); ctx->ipv.release();
     for (auto &sl : ctx->slots) {
-        sl.queues.release(); sl.spill.release(); sl.item_cost.release(); sl.item_order.release();
+        sl.queues.release(); sl.spill.release();
         if (sl.ev_start) (void)hipEventDestroy(sl.ev_start);
         if (sl.ev_stop) (void)hipEventDestroy(sl.ev_stop);
     }
@@ -427,9 +398,6 @@ int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value) {
     } else if (!std::strcmp(name, "leaf_thresh")) {
         if (value < 1 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "leaf_thresh must be 1..64");
         ctx->leaf_thresh = (uint32_t)value;
-    } else if (!std::strcmp(name, "prio_thresh")) {
-        if (value < 0 || value > (1 << 24)) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "prio_thresh must be 0..2^24");
-        ctx->prio_thresh = (uint32_t)value;
     } else if (!std::strcmp(name, "queue_stride")) {
         if (value < 1 || value > 4096) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "queue_stride must be 1..4096 words");
         ctx->queue_stride = (uint32_t)value;
@@ -440,19 +408,10 @@ int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value) {
     } else if (!std::strcmp(name, "max_blocks_per_cu")) {
         if (value < 0 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "max_blocks_per_cu must be 0..64");
         ctx->max_blocks_per_cu = (uint32_t)value;
-    } else if (!std::strcmp(name, "chunk")) {
-        if (value < 1 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "chunk must be 1..64");
-        ctx->chunk = (uint32_t)value;
-    } else if (!std::strcmp(name, "heavy_factor_x4")) {
-        if (value < 0 || value > 1024) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "heavy_factor_x4 must be 0..1024");
-        ctx->heavy_num = (uint32_t)value;
     } else if (!std::strcmp(name, "launch_timing")) {
         ctx->launch_timing = value != 0;
     } else if (!std::strcmp(name, "shadow_anyhit")) {
         ctx->shadow_anyhit = value != 0;
-    } else if (!std::strcmp(name, "adaptive_order")) {
-        ctx->adaptive_order = value != 0;
-        for (auto &sl : ctx->slots) sl.order_items[0] = sl.order_items[1] = 0;
     } else if (!std::strcmp(name, "num_queues")) {
         if (value < 1 || value > 32) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "num_queues must be 1..32");
         ctx->n_queues = (uint32_t)value;

@@ -61,15 +61,10 @@ def main():
             tr.set_option("dyn_thresh", int(o.get("dyn_thresh", 0)))
             tr.set_option("num_queues", int(o.get("num_queues", 8)))
             tr.set_option("leaf_thresh", int(o.get("leaf_thresh", 8)))
-            tr.set_option("prio_thresh", int(o.get("prio_thresh", 0)))
             tr.set_option("queue_stride", int(o.get("queue_stride", 64)))
-            tr.set_option("chunk", int(o.get("chunk", 1)))
             tr.set_option("max_blocks_per_cu", int(o.get("blocks", 0)))
             tr.set_option("queue_block", int(o.get("queue_block", 256 if o.get("mode", "fused") == "fused" else 1)))
-            tr.set_option("heavy_factor_x4", int(o.get("heavy", 8)))
             tr.set_option("shadow_anyhit", int(o.get("anyhit", 1)))
-            if "adaptive" in o:
-                tr.set_option("adaptive_order", int(o["adaptive"]))
             mode = o.get("mode", "fused")
             if args.inflight > 1:
                 for rep in range(2):

@@ -19,8 +19,6 @@ d_rgba = torch.zeros((n, 4), dtype=torch.float32, device=dev)
 tr.set_option('leaf_thresh', 8)
 prev_dur = prev_ok = None
 for th, nq, ad, pr in ((1, 8, 0, 0),):
-    tr.set_option('heavy_factor_x4', 8)
-    tr.set_option('adaptive_order', ad); tr.set_option('prio_thresh', pr); print(f'--- prio_thresh {pr}')
     tr.set_option("dyn_thresh", th); tr.set_option("num_queues", nq)
     for _ in range(3):
         tr.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=model.has_tex_coords(), has_normals=model.has_normals(), rgba_ptr=d_rgba.data_ptr())
