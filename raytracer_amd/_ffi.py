@@ -142,6 +142,15 @@ def device_lib():
         if not os.path.exists(DEVICE_LIB_PATH):
             raise RuntimeError(f"{DEVICE_LIB_PATH} is missing: the HIP library must be built "
                                f"(`make -C raytracer_amd/csrc device`); there is no CPU fallback")
+        # One HIP runtime per process.  torch ships its own libamdhip64.so.7 and librtamd.so asks for the
+        # system one by the same SONAME, so whichever is loaded first serves both — and torch's device
+        # initialisation fails ("No HIP GPUs are available") on top of the system copy.  Python callers of this
+        # package use torch for device buffers and streams, so let torch bring its runtime in first.
+        if os.environ.get("RTAMD_NO_TORCH_PRELOAD") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = ctypes.CDLL(DEVICE_LIB_PATH)
         vp = ctypes.c_void_p
         L.rtamd_context_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]

@@ -149,9 +149,10 @@ __device__ __forceinline__ float aabb_dist(const Ray &r, float minx, float miny,
 // predicate, so lanes of a wave never diverge inside a triangle test.
 __device__ __forceinline__ void tri_test(const Ray &r, const TriRecord *__restrict__ rec, uint32_t i, float &best_t,
                                          uint32_t &best_idx, float &best_u, float &best_v) {
-    const float4 r0 = *reinterpret_cast<const float4 *>(&rec[i].p0[0]);
-    const float4 r1 = *reinterpret_cast<const float4 *>(&rec[i].e1[1]);
-    const float r2 = rec[i].e2[2];
+    const char *rp = reinterpret_cast<const char *>(rec) + i * (uint32_t)sizeof(TriRecord);   // 32-bit offset, as for the nodes
+    const float4 r0 = *reinterpret_cast<const float4 *>(rp);
+    const float4 r1 = *reinterpret_cast<const float4 *>(rp + 16);
+    const float r2 = *reinterpret_cast<const float *>(rp + 32);
     const float p0x = r0.x, p0y = r0.y, p0z = r0.z;
     const float e1x = r0.w, e1y = r1.x, e1z = r1.y;
     const float e2x = r1.z, e2y = r1.w, e2z = r2;
@@ -322,7 +323,9 @@ __device__ __forceinline__ uint32_t touch_ref(const SceneDev &s, uint32_t ref) {
 // Vector fetch: every lane loads its own 64-byte record (4 x global_load_dwordx4).
 template <bool COUNT, int OCT = -1, class Stack>
 __device__ __forceinline__ void trav_inner(const SceneDev &s, Trav &tr, Stack &st, uint32_t tid, uint32_t &nbox) {
-    const float4 *np = reinterpret_cast<const float4 *>(&s.nodes[tr.cur]);
+    // 32-bit byte offset from the (scalar) base: the loads take the base in SGPRs and one VGPR offset,
+    // instead of a 64-bit per-lane address (upload checks that nodes + triangle records stay below 4 GiB)
+    const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.nodes) + (tr.cur << 6));
     const float4 q0 = np[0], q1 = np[1], q2 = np[2];
     const uint2 refs = *reinterpret_cast<const uint2 *>(&np[3]);
 #if RTAMD_PREFETCH

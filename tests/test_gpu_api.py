@@ -66,6 +66,22 @@ def test_errors():
         t.close()
 
 
+def test_library_first_then_torch_in_a_fresh_process():
+    """Load order: a process that creates the tracer before it ever imports torch must still be able to use
+    torch on the GPU (one HIP runtime per process, raytracer_amd/_ffi.py)."""
+    import subprocess, sys, os
+    code = ("import numpy as np\n"
+            "from raytracer_amd.renderer import HipRayTracer\n"
+            "t = HipRayTracer(0)\n"
+            "import torch\n"
+            "x = torch.arange(8, device='cuda:0', dtype=torch.float32)\n"
+            "assert float(x.sum()) == 28.0\n"
+            "t.close(); print('ok')\n")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=repo, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_launch_timing_option(tracer):
     g = load_golden("cube")
     tracer.upload_scene(g["scene"])
