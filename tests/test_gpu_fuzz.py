@@ -1,0 +1,105 @@
+"""Randomised parity: many small scenes built by the host BVH builder from adversarial geometry, traced
+with adversarial rays, GPU (both kernel variants) against oracle A, bit for bit.
+
+What the generators aim at: exact ties (duplicated triangles, shared edges and vertices hit exactly),
+zero-size boxes (axis-aligned geometry), rays with zero direction components (infinite reciprocals:
+the general slab path instead of the octant path), origins on box faces and inside the scene,
+degenerate (zero-area) triangles, huge and tiny coordinates, denormal inputs (flushed), NO_RAY
+entries, and every work-item raggedness the queue sees (ray counts that are not multiples of 64)."""
+import numpy as np
+import pytest
+
+from common import bits, rgb_err_255
+from raytracer_amd import host
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(rng, kind):
+    n = int(rng.integers(1, 400))
+    if kind == "grid":          # axis-aligned quads on an integer lattice: flat boxes, shared edges, exact ties
+        c = rng.integers(-4, 5, (n, 3)).astype(np.float32)
+        axis = rng.integers(0, 3, n)
+        u = np.eye(3, dtype=np.float32)[(axis + 1) % 3]
+        v = np.eye(3, dtype=np.float32)[(axis + 2) % 3]
+        tri_pos = np.stack([c, c + u, c + v], axis=1)
+    elif kind == "dup":         # few distinct triangles, each repeated: ties resolved by traversal order only
+        base = rng.uniform(-3, 3, (max(1, n // 8), 3, 3)).astype(np.float32)
+        tri_pos = base[rng.integers(0, len(base), n)]
+    elif kind == "degenerate":  # zero-area and needle triangles among ordinary ones
+        tri_pos = rng.uniform(-3, 3, (n, 3, 3)).astype(np.float32)
+        k = rng.random(n)
+        tri_pos[k < 0.2, 2] = tri_pos[k < 0.2, 1]
+        tri_pos[(k >= 0.2) & (k < 0.3), 1] = tri_pos[(k >= 0.2) & (k < 0.3), 0]
+    elif kind == "scales":      # 1e-30 .. 1e6 coordinates, denormal vertices
+        tri_pos = (rng.uniform(-1, 1, (n, 3, 3)) * 10.0 ** rng.uniform(-30, 6, (n, 1, 1))).astype(np.float32)
+        tri_pos[rng.random(n) < 0.1] *= np.float32(1e-40 / 1e-30)
+    else:                       # plain soup
+        tri_pos = rng.uniform(-3, 3, (n, 3, 3)).astype(np.float32)
+    pos = tri_pos.reshape(-1, 3)
+    tri = np.concatenate([np.arange(3 * n, dtype=np.uint32).reshape(n, 3), rng.integers(0, 2, (n, 1)).astype(np.uint32)], axis=1)
+    m = host.Model.from_arrays(tri, pos)
+    m.build_bvh()
+    return m.scene_arrays(), tri_pos
+
+
+def _rays(rng, tri_pos, n):
+    k = len(tri_pos)
+    # aim at exact vertices / edge points / interior points of random triangles
+    t = tri_pos[rng.integers(0, k, n)].astype(np.float64)
+    w = rng.dirichlet([1, 1, 1], n)
+    sel = rng.random(n)
+    w[sel < 0.15] = np.eye(3)[rng.integers(0, 3, int((sel < 0.15).sum()))]                 # a vertex
+    e = (sel >= 0.15) & (sel < 0.3)
+    w[e, 2] = 0.0; w[e, :2] /= np.maximum(w[e, :2].sum(1, keepdims=True), 1e-30)         # on an edge
+    target = (t * w[:, :, None]).sum(1)
+    org = rng.uniform(-6, 6, (n, 3))
+    inside = rng.random(n) < 0.2
+    org[inside] = target[inside] + rng.uniform(-0.5, 0.5, (int(inside.sum()), 3))           # origins inside the scene's boxes
+    lattice = rng.random(n) < 0.3
+    org[lattice] = np.round(org[lattice])                                                   # on lattice planes = on box faces of the grid scenes
+    d = target - org
+    axis_aligned = rng.random(n) < 0.25                                                     # zero components: infinite reciprocals
+    a = rng.integers(0, 3, n)
+    for i in np.where(axis_aligned)[0]:
+        keep = d[i, a[i]] if d[i, a[i]] != 0 else 1.0
+        d[i] = 0.0; d[i, a[i]] = keep
+    planar = (~axis_aligned) & (rng.random(n) < 0.15)
+    d[planar, rng.integers(0, 3)] = 0.0
+    nrm = np.linalg.norm(d, axis=1, keepdims=True)
+    d = np.where(nrm > 0, d / np.maximum(nrm, 1e-300), [[0.0, 0.0, 1.0]])
+    unnorm = rng.random(n) < 0.1
+    d[unnorm] *= rng.uniform(1e-3, 1e3, (int(unnorm.sum()), 1))                            # the shaders do not require unit directions
+    org = org.astype(np.float32); d = d.astype(np.float32)
+    d[rng.random(n) < 0.02] = 0.0                                                           # NO_RAY (ray_trace.frag:133)
+    neg0 = rng.random(n) < 0.05
+    d[neg0] = np.where(d[neg0] == 0, np.float32(-0.0), d[neg0])
+    return org, d
+
+
+@pytest.mark.parametrize("kind", ["grid", "dup", "degenerate", "scales", "soup"])
+def test_random_scenes_trace_and_fused_match_oracle(tracer, oracle_a, kind):
+    rng = np.random.default_rng({"grid": 11, "dup": 12, "degenerate": 13, "scales": 14, "soup": 15}[kind])
+    white = np.full((1, 1, 3), 255, np.uint8)
+    tracer.upload_texture(0, white); tracer.upload_texture(1, white)
+    try:
+        for rep in range(12):
+            sc, tri_pos = _scene(rng, kind)
+            n = int(rng.integers(1, 3000))
+            org, d = _rays(rng, tri_pos, n)
+            tracer.upload_scene(sc)
+            want = oracle_a.trace(sc, org, d)["hits"]
+            lit = d.any(axis=1)                                  # the fused shader has no NO_RAY convention: give those a direction
+            d2 = d.copy(); d2[~lit] = np.float32([0, 0, 1])
+            a = oracle_a.render(sc, d2, org, 0, 0)
+            for variant in (0, 1):
+                tracer.set_kernel_variant(variant)
+                got = tracer.trace(org, d)
+                assert np.array_equal(bits(got), bits(want)), (kind, rep, variant, int((bits(got) != bits(want)).any(axis=1).sum()))
+                r = tracer.render(n, 1, dir=d2, org=org, has_tex_coords=0, has_normals=0)
+                assert np.array_equal(a["hit_id"], r["hit_id"]) and np.array_equal(bits(a["hit_t"]), bits(r["hit_t"])), (kind, rep, variant)
+                ok = np.isfinite(a["rgba"]).all(axis=1) & np.isfinite(r["rgba"]).all(axis=1)
+                assert np.array_equal(np.isfinite(a["rgba"]), np.isfinite(r["rgba"]))
+                assert rgb_err_255(a["rgba"][ok], r["rgba"][ok]).max(initial=0.0) <= 0.05, (kind, rep, variant)
+    finally:
+        tracer.set_kernel_variant(0)
