@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=16
 out=gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline "$@" > "$out/trace.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --no-cpu-baseline "$@" > "$out/trace.log" 2>&1
 pass() {
   name=$1; shift
   timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$out/pmc_$name" -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline $BENCH_ARGS > "$out/pmc_$name.log" 2>&1
