@@ -305,8 +305,9 @@ int rtamd_set_kernel_variant(rtamd_context *ctx, int variant);
  *  "num_queues" 1..32   work-queue counters (8 = one per XCD);
  *  "queue_stride" 1..4096  u32 words between the counters (default 64 = 256 B, one memory
  *                       channel each);
- *  "max_blocks_per_cu" 0..64  cap on resident workgroups per CU (0 = all that fit, 8); 6 is 2.5-4 % faster on
- *                       incoherent rays, 8 on coherent ones;
+ *  "max_blocks_per_cu" 0..64  cap on the persistent grid, in workgroups per CU.  0 (default) = automatic: all that
+ *                       fit (8) for a launch on its own, 16 / n when n launches of this context are in flight on
+ *                       different streams, so that the grids of overlapping frames are resident side by side;
  *  "queue_block" 1..65536  consecutive schedule positions (work items) a queue owns per turn, i.e. the size of
  *                       the screen region the waves of one XCD share (default 256 for frames, 1 for ray lists);
  *  "launch_timing" 0/1  record a start event in front of every launch (default 1); 0 saves one

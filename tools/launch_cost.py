@@ -13,11 +13,13 @@ d_org = torch.tensor(np.asarray(camera.position, np.float32), device=dev).repeat
 streams = [torch.cuda.Stream(device=dev) for _ in range(8)]
 timing = int(os.environ.get("LAUNCH_TIMING", "1"))
 tr.set_option("launch_timing", timing)
-print("launch_timing", timing)
+blocks = int(os.environ.get("BLOCKS", "0"))
+tr.set_option("max_blocks_per_cu", blocks)
+print("launch_timing", timing, "max_blocks_per_cu", blocks)
 for world in (1, 2, 4, 8):
     per = tr.tiles_per_rank(W, H, world) * 1024
     outs = [torch.zeros((per if world > 1 else n, 4), dtype=torch.float32, device=dev) for _ in range(8)]
-    for S in (1, 2, 4, 6, 8):
+    for S in ((1, 2, 4, 6, 8) if not os.environ.get('STREAMS') else tuple(int(x) for x in os.environ['STREAMS'].split(','))):
         K = 400
         for rep in range(2):
             torch.cuda.synchronize(); t0 = time.perf_counter()
