@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames issued round-robin on that many streams (1 = serial; 0 = auto: 4 on one GPU, 8 with tiles split over "
                          "several GPUs, where a launch covers 1/N of the frame and is bounded by its slowest rays, not by throughput)")
+    ap.add_argument("--gather-batch", type=int, default=0,
+                    help="N > 1: frames per RCCL gather (0 = auto: 4 up to 1080p, 1 above)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -161,14 +163,21 @@ def main():
     scene_mb = (info.inner_node_count * 64 + info.triangle_count * 48) / 1e6
     F = args.frames_in_flight if args.frames_in_flight > 0 else (2 if scene_mb > 256 else 4 if world == 1 else 8)
     F = max(1, min(8, F))
-    # frame k renders on render_streams[k % F] into rgba[k % F]; gather + assembly stay on `stream`
+    # One GPU: frame k renders on render_streams[k % F] into rgba[k % F].
+    # N > 1: frames are gathered in batches of G (one collective per G frames: the call costs the root's host
+    # 13+ us, a third of the 39 us a 1/8 share of this frame takes).  Batch j = frames jG .. jG+G-1 renders on
+    # render_streams[j % F], back to back, into batch buffer j % F ([G][n_local_out] pixels); `stream` then waits
+    # for that stream, gathers the buffer, assembles the G scan-line frames and marks the buffer free.
+    G = 1
+    if world > 1:
+        G = args.gather_batch if args.gather_batch > 0 else (4 if n_px <= 1920 * 1080 else 1)
     render_streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(F - 1)]
-    rgba = [torch.zeros((n_local_out, 4), dtype=torch.float32, device=dev) for _ in range(F)]
-    consumed = [torch.cuda.Event() for _ in range(F)]   # frame in rgba[f] has been gathered
+    rgba = [torch.zeros((G * n_local_out, 4), dtype=torch.float32, device=dev) for _ in range(F)]
+    consumed = [torch.cuda.Event() for _ in range(F)]   # batch buffer f has been gathered
     d_rgba = rgba[0]
-    if F == 2:
-        # HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES = 4 here) and two streams that
-        # share one cannot overlap: try a handful of partner streams and keep the one that overlaps best.
+    if F == 2 and world == 1:
+        # two streams that share a hardware queue cannot overlap: try a handful of partner streams and keep
+        # the one that overlaps best (only matters when GPU_MAX_HW_QUEUES is left at a small value)
         def pair_ms(partner, frames=16):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -185,15 +194,40 @@ def main():
         tracer.set_stream(stream.cuda_stream)
     frame = None
     if world > 1 and rank == 0:
-        gathered_flat = torch.empty((world * n_local_out, 4), dtype=torch.float32, device=dev)
-        frame = torch.empty((n_px, 4), dtype=torch.float32, device=dev)
+        gathered = torch.empty((world, G * n_local_out, 4), dtype=torch.float32, device=dev)   # [rank][frame of the batch][pixel]
+        frames_out = torch.empty((G, n_px, 4), dtype=torch.float32, device=dev)
+        frame = frames_out[0]
     launch_events = []
+    pending = [None]   # batch buffer that holds rendered frames not gathered yet
+
+    def flush(f):
+        """Gather batch buffer f (all ranks call this at the same step) and assemble its frames on the root."""
+        rs = render_streams[f]
+        if rs is not stream:
+            stream.wait_stream(rs)
+        if rehearse:
+            stream.synchronize()
+            mine = rgba[f].cpu()
+            parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+            dist.gather(mine, gather_list=parts, dst=0)
+            if rank == 0:
+                gathered.copy_(torch.stack(parts))
+        elif rank == 0:
+            dist.gather(rgba[f], gather_list=list(gathered.unbind(0)), dst=0)
+        else:
+            dist.gather(rgba[f], dst=0)
+        if rank == 0:
+            tracer.set_stream(stream.cuda_stream)
+            tracer.assemble_tile_batch_device(gathered.data_ptr(), W, H, world, 4, G, frames_out.data_ptr())
+        consumed[f].record(stream)
+        pending[0] = None
 
     def step(k, timed=False):
-        f = k % F
+        batch, g = divmod(k, G)
+        f = batch % F
         rs = render_streams[f]
-        if world > 1 and F > 1 and k >= F:
-            rs.wait_event(consumed[f])          # rgba[f] is free again once frame k-F has been gathered
+        if world > 1 and g == 0 and batch >= F:
+            rs.wait_event(consumed[f])          # the buffer is free again once batch - F has been gathered
         tracer.set_stream(rs.cuda_stream)
         # launch durations for the roofline: every launch on one GPU; with N > 1 the host has ~40 us per step
         # for everything (render call, gather, assembly), so only every 8th launch carries the two extra events
@@ -202,29 +236,14 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(rs)
         tracer.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=has_tc, has_normals=has_n,
-                             tile_rank=rank, tile_world=world, rgba_ptr=rgba[f].data_ptr())
+                             tile_rank=rank, tile_world=world, rgba_ptr=rgba[f].data_ptr() + g * n_local_out * 16)
         if timed:
             e1.record(rs)
             launch_events.append((e0, e1))
         if world > 1:
-            if F > 1:
-                stream.wait_stream(rs)
-            if rehearse:
-                stream.synchronize()
-                mine = rgba[f].cpu()
-                parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-                dist.gather(mine, gather_list=parts, dst=0)
-                if rank == 0:
-                    gathered_flat.copy_(torch.cat(parts))
-            elif rank == 0:
-                dist.gather(rgba[f], gather_list=list(gathered_flat.view(world, n_local_out, 4).unbind(0)), dst=0)
-            else:
-                dist.gather(rgba[f], dst=0)
-            if rank == 0:
-                tracer.set_stream(stream.cuda_stream)
-                tracer.assemble_tiles_device(gathered_flat.data_ptr(), W, H, world, 4, frame.data_ptr())
-            if F > 1:
-                consumed[f].record(stream)
+            pending[0] = f
+            if g == G - 1:
+                flush(f)
 
     # ---- untimed: per-pixel counters of the whole frame (rank-local share) for the roofline
     d_counts = torch.zeros((n_local_out, 2), dtype=torch.int32, device=dev)
@@ -257,6 +276,8 @@ def main():
     torch.cuda.synchronize()
     for k in range(args.warmup):
         step(k)
+    if pending[0] is not None:
+        flush(pending[0])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -266,8 +287,11 @@ def main():
     ev0.record(stream)
     for k in range(args.steps):
         step(k, timed=True)
+    if pending[0] is not None:
+        flush(pending[0])       # the last, partial batch: all K frames are gathered and assembled inside the timed region
     for rs in render_streams:
-        stream.wait_stream(rs)
+        if rs is not stream:
+            stream.wait_stream(rs)
     ev1.record(stream)
     torch.cuda.synchronize()
     if world > 1:
@@ -296,7 +320,8 @@ def main():
         full = torch.zeros((n_px, 4), dtype=torch.float32, device=dev)
         tracer.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=has_tc, has_normals=has_n, rgba_ptr=full.data_ptr())
         torch.cuda.synchronize()
-        frame_check = bool(torch.equal(full.view(torch.int32), frame.view(torch.int32)))
+        n_last = (args.steps - 1) % G + 1      # frames the last gathered batch holds
+        frame_check = all(bool(torch.equal(full.view(torch.int32), frames_out[i].view(torch.int32))) for i in range(n_last))
 
     ms_per_step = elapsed * 1e3 / args.steps
     value = rays_per_frame * args.steps / elapsed / 1e6
@@ -319,7 +344,7 @@ def main():
                                f"{W}x{H}, 1 spp, primary + sun shadow ray + shading (fused ray_trace_and_shade semantics)",
                    "rays_per_frame": rays_per_frame, "primary_rays": n_primary_all, "shadow_rays": n_shadow_all,
                    "parallelism": f"tiles{world}" if world > 1 else "single", "kernel_variant": args.variant,
-                   "frames_in_flight": F, "shadow_rays_stop_at_first_occluder": True,
+                   "frames_in_flight": F, **({"frames_per_gather": G} if world > 1 else {}), "shadow_rays_stop_at_first_occluder": True,
                    **({"assembled_frame_equals_single_gpu_frame": frame_check} if frame_check is not None else {}),
                    **({"REHEARSAL_not_a_measurement": "all ranks on cuda:0, gloo gather through host memory"} if rehearse else {}),
                    "bvh_build_s": round(build_s, 2)},

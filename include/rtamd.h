@@ -267,6 +267,12 @@ uint32_t rtamd_tiles_per_rank(uint32_t width, uint32_t height, uint32_t tile_wor
 int rtamd_assemble_tiles_device(rtamd_context *ctx, const void *gathered, uint32_t width, uint32_t height,
                                 uint32_t tile_world, uint32_t elems_per_pixel, void *frame_out);
 
+/* The same for a batch of n_frames frames moved by ONE gather (a rank sends its shares of n_frames
+ * consecutive frames as one block, which divides the per-frame cost of the collective by n_frames):
+ * `gathered` is [rank][frame][rtamd_tiles_per_rank()*1024 pixels], `frames_out` [frame][height*width]. */
+int rtamd_assemble_tile_batch_device(rtamd_context *ctx, const void *gathered, uint32_t width, uint32_t height,
+                                     uint32_t tile_world, uint32_t elems_per_pixel, uint32_t n_frames, void *frames_out);
+
 /* ---- introspection ---------------------------------------------------------- */
 
 typedef struct rtamd_scene_info {

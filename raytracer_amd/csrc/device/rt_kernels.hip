@@ -1058,16 +1058,19 @@ __global__ void __launch_bounds__(256) k_dispatch_rays(const DispatchParams p) {
     }
 }
 
-// Root side of the gather: rank-major tile blocks -> scan-line frame.
+// Root side of the gather: rank-major tile blocks -> scan-line frame(s).  blockIdx.y = frame f of a batch:
+// `gathered` is [rank][frame][tiles_per_rank * 1024 pixels], `out` is [frame][height * width].
 __global__ void k_assemble_tiles(const uint32_t *__restrict__ gathered, uint32_t width, uint32_t height, uint32_t world,
                                  uint32_t tiles_x, uint32_t tiles_per_rank, uint32_t elems, uint32_t *__restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= width * height) return;
+    const uint32_t f = blockIdx.y, n_frames = gridDim.y;
     uint32_t x = i % width, y = i / width;
     uint32_t g = (y >> 5) * tiles_x + (x >> 5);
     uint32_t r = g % world, j = g / world;
-    size_t src = ((size_t)r * tiles_per_rank + j) * RTAMD_TILE_PIXELS + ((y & 31u) * 32u + (x & 31u));
-    for (uint32_t e = 0; e < elems; e++) out[(size_t)i * elems + e] = gathered[src * elems + e];
+    size_t src = (((size_t)r * n_frames + f) * tiles_per_rank + j) * RTAMD_TILE_PIXELS + ((y & 31u) * 32u + (x & 31u));
+    size_t dst = (size_t)f * width * height + i;
+    for (uint32_t e = 0; e < elems; e++) out[dst * elems + e] = gathered[src * elems + e];
 }
 
 }  // namespace rtamd

@@ -900,10 +900,11 @@ uint32_t rtamd_tiles_per_rank(uint32_t width, uint32_t height, uint32_t tile_wor
     return local_tiles(n_tiles_of(width, height, nullptr), 0, tile_world);
 }
 
-int rtamd_assemble_tiles_device(rtamd_context *ctx, const void *gathered, uint32_t width, uint32_t height,
-                                uint32_t tile_world, uint32_t elems_per_pixel, void *frame_out) {
+int rtamd_assemble_tile_batch_device(rtamd_context *ctx, const void *gathered, uint32_t width, uint32_t height,
+                                     uint32_t tile_world, uint32_t elems_per_pixel, uint32_t n_frames, void *frames_out) {
     if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
-    if (!gathered || !frame_out || width == 0 || height == 0 || tile_world == 0 || elems_per_pixel == 0 || elems_per_pixel > 4)
+    if (!gathered || !frames_out || width == 0 || height == 0 || tile_world == 0 || elems_per_pixel == 0 || elems_per_pixel > 4 ||
+        n_frames == 0 || n_frames > 65535u || (uint64_t)width * height > 0x7FFFFFFFull)
         return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "bad assemble_tiles arguments");
     int rc = ensure_ctx_device(ctx);
     if (rc) return rc;
@@ -911,10 +912,15 @@ int rtamd_assemble_tiles_device(rtamd_context *ctx, const void *gathered, uint32
     uint32_t n_tiles = n_tiles_of(width, height, &tiles_x);
     uint32_t per_rank = local_tiles(n_tiles, 0, tile_world);
     uint32_t n = width * height;
-    hipLaunchKernelGGL(k_assemble_tiles, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t *)gathered, width, height,
-                       tile_world, tiles_x, per_rank, elems_per_pixel, (uint32_t *)frame_out);
+    hipLaunchKernelGGL(k_assemble_tiles, dim3((n + 255) / 256, n_frames), dim3(256), 0, ctx->stream, (const uint32_t *)gathered, width, height,
+                       tile_world, tiles_x, per_rank, elems_per_pixel, (uint32_t *)frames_out);
     HIP_TRY(ctx, hipGetLastError());
     return RTAMD_OK;
+}
+
+int rtamd_assemble_tiles_device(rtamd_context *ctx, const void *gathered, uint32_t width, uint32_t height,
+                                uint32_t tile_world, uint32_t elems_per_pixel, void *frame_out) {
+    return rtamd_assemble_tile_batch_device(ctx, gathered, width, height, tile_world, elems_per_pixel, 1, frame_out);
 }
 
 int rtamd_get_scene_info(const rtamd_context *ctx, rtamd_scene_info *info) {

@@ -266,6 +266,12 @@ class HipRayTracer:
                                                           elems_per_pixel, ctypes.c_void_p(frame_ptr)))
 
 
+    def assemble_tile_batch_device(self, gathered_ptr, width, height, tile_world, elems_per_pixel, n_frames, frames_ptr):
+        """gathered [rank][frame][tiles_per_rank*1024 px] -> frames [frame][height*width px] (one gather per batch of frames)."""
+        self._check(self._lib.rtamd_assemble_tile_batch_device(self._h, ctypes.c_void_p(gathered_ptr), width, height, tile_world,
+                                                               elems_per_pixel, n_frames, ctypes.c_void_p(frames_ptr)))
+
+
 def assemble_tiles_host(blocks, width, height, tile_world, elems):
     """Pure-numpy statement of the tile layout (used by CPU tests of the sharding
     logic): blocks[r] is rank r's compact tile-major array (n_local*1024, elems)."""

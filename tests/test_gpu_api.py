@@ -227,6 +227,14 @@ def test_tile_shards_assemble_to_the_full_frame(tracer, world):
     tracer.assemble_tiles_device(gathered.data_ptr(), w, h, world, 4, out.data_ptr())
     tracer.synchronize()
     assert np.array_equal(bits(out.cpu().numpy()), bits(full["rgba"]))
+    # a batch of 3 frames moved by one gather: [rank][frame][pixels] -> [frame][scan lines]; frame f is the frame scaled by f + 1
+    blocks = np.stack([np.stack([pad(p["rgba"]) * np.float32(f + 1) for f in range(3)]) for p in parts])
+    gathered = torch.from_numpy(blocks).cuda()
+    outs = torch.zeros((3, w * h, 4), dtype=torch.float32, device="cuda")
+    tracer.assemble_tile_batch_device(gathered.data_ptr(), w, h, world, 4, 3, outs.data_ptr())
+    tracer.synchronize()
+    for f in range(3):
+        assert np.array_equal(bits(outs[f].cpu().numpy()), bits(full["rgba"] * np.float32(f + 1)))
 
 
 def test_on_device_ray_generation_equals_host_and_oracle(tracer, oracle_a):
