@@ -5,7 +5,7 @@ Sponza-class atrium, 3840x2160, S samples per pixel, depth <= 3.  Per sample: ji
 (ray_dispatcher.frag) emits a shadow ray to a point light and one continuation — the mirror direction for even
 sample indices, the ambient direction normalize(n + noise*2-1) for odd ones — and rtamd_surface_from_hits_device
 turns the continuation's hit records into the next G-buffer.  Every stage is parity-tested against the oracle
-(tests/test_gpu_parity.py).  Samples alternate over two streams with their own buffers (frames in flight).
+(tests/test_gpu_parity.py).  Samples rotate over --lanes streams with their own buffers (frames in flight).
 A ray = one traversal that was actually started (NO_RAY entries are not counted).
 Usage: tools/bench_c5.py [--spp 8] [--width 3840 --height 2160] [--depth 3]"""
 import argparse, json, os, sys, time
@@ -21,6 +21,7 @@ ap.add_argument("--spp", type=int, default=8)
 ap.add_argument("--width", type=int, default=3840)
 ap.add_argument("--height", type=int, default=2160)
 ap.add_argument("--depth", type=int, default=3)
+ap.add_argument("--lanes", type=int, default=4, help="samples in flight (streams)")
 args = ap.parse_args()
 W, H, n = args.width, args.height, args.width * args.height
 dev = torch.device("cuda", 0)
@@ -48,7 +49,7 @@ class Lane:   # one sample in flight: a stream and its buffers
         self.rays = torch.zeros((), dtype=torch.int64, device=dev)
 
 
-lanes = [Lane(), Lane()]
+lanes = [Lane() for _ in range(max(1, min(8, args.lanes)))]
 G = 0.7548776662466927   # R2 sequence (plastic number)
 
 
@@ -80,19 +81,19 @@ def sample(s, lane):
                 org, d = lane.org3, lane.dir2
 
 
-for s in range(2):
-    sample(s, lanes[s % 2])
+for s in range(len(lanes)):
+    sample(s, lanes[s % len(lanes)])
 torch.cuda.synchronize()
 for l in lanes:
     l.rays.zero_()
 t0 = time.perf_counter()
 for s in range(args.spp):
-    sample(s, lanes[s % 2])
+    sample(s, lanes[s % len(lanes)])
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 rays = int(sum(int(l.rays.item()) for l in lanes))
 print(json.dumps({"metric": "Mrays/s", "value": round(rays / dt / 1e6, 1), "unit": "Mrays/s", "n_gpus": 1,
                   "config": {"workload": f"C5: atrium {len(sc['triangles'])} triangles, {W}x{H}, {args.spp} spp, depth <= {args.depth}, "
                                          "primary + (shadow + mirror|ambient continuation) per bounce", "rays": rays,
-                             "rays_per_pixel_sample": round(rays / (n * args.spp), 3), "samples_in_flight": 2},
+                             "rays_per_pixel_sample": round(rays / (n * args.spp), 3), "samples_in_flight": len(lanes)},
                   "seconds": round(dt, 4), "ms_per_sample_frame": round(dt / args.spp * 1e3, 3), "data": "synthetic", "dtype": "f32"}))
