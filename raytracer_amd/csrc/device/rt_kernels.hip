@@ -188,7 +188,6 @@ struct Trav {
     uint32_t cur;   // node reference being visited, REF_NONE when the traversal is finished
     uint32_t sp;    // deferred references on this lane's stack (Stack policy's representation)
     uint32_t sb;    // StackGlobal: entries moved out to HBM (same representation); else unused
-    uint32_t pf0, pf1;  // landing registers of the prefetch touches (kept live until the next visit)
 };
 
 // Stack policies.  Entry e of thread tid lives at lds[e*BLOCK + tid] (ds_read/write_b32:
@@ -304,21 +303,9 @@ __device__ __forceinline__ void trav_select(Trav &tr, Stack &st, uint32_t tid, b
     else tr.cur = st.empty(tr.sp) ? REF_NONE : st.pop(tid, tr.sp, tr.sb);
 }
 
-// Touch-prefetch: one dword load from the record a child reference points to (node
-// record or first triangle record) pulls its cache line towards this CU's L1 while
-// the box tests of the current visit execute; the value is never used.
-// Measured on MI355X (tools/kbench.py, atrium 1080p): the two extra divergent dword
-// loads per visit cost more L1 tag look-ups than the latency they hide is worth
-// (k_static 0.59 -> 0.90 ms, k_persistent 0.55 -> 0.61 ms), i.e. the traversal is bound
-// by the vector-memory address/tag pipeline, not by load latency.  Kept for A/B only.
-#ifndef RTAMD_PREFETCH
-#define RTAMD_PREFETCH 0
-#endif
-__device__ __forceinline__ uint32_t touch_ref(const SceneDev &s, uint32_t ref) {
-    const uint32_t off = (ref & REF_LEAF_BIT) ? s.tri_byte_offset + (ref & REF_FIRST_MASK) * (uint32_t)sizeof(TriRecord)
-                                              : ref * (uint32_t)sizeof(WideNode);
-    return *reinterpret_cast<const volatile uint32_t *>(reinterpret_cast<const char *>(s.nodes) + off);
-}
+// (Touch-prefetch — one dword load from each child's record while the box tests run — was measured and
+// removed: the two extra divergent loads per visit cost more L1 accesses than the latency they hide,
+// k_static 0.59 -> 0.90 ms, k_persistent 0.55 -> 0.61 ms; re-measured later: 18 % slower.)
 
 // Vector fetch: every lane loads its own 64-byte record (4 x global_load_dwordx4).
 template <bool COUNT, int OCT = -1, class Stack>
@@ -328,14 +315,6 @@ __device__ __forceinline__ void trav_inner(const SceneDev &s, Trav &tr, Stack &s
     const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.nodes) + (tr.cur << 6));
     const float4 q0 = np[0], q1 = np[1], q2 = np[2];
     const uint2 refs = *reinterpret_cast<const uint2 *>(&np[3]);
-#if RTAMD_PREFETCH
-    // keep the previous visit's landing registers allocated until here (their loads are
-    // older than the four above, so no extra wait), then re-use them for this visit
-    asm volatile("" ::"v"(tr.pf0), "v"(tr.pf1));
-    // big-leaf references (count field 0) index the overflow table, not a triangle: harmless, in-bounds touch
-    tr.pf0 = touch_ref(s, refs.x);
-    tr.pf1 = touch_ref(s, refs.y);
-#endif
     if (COUNT) nbox += 2;
     float tmin0, tmin1;
     const bool hit0 = slab_sel<OCT>(tr.ray, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tr.t, tmin0);
@@ -661,7 +640,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
     uint32_t stat_inner = 0, stat_uniform = 0, stat_lanes = 0;
     uint32_t phase = PH_IDLE;
     Trav tr;
-    tr.cur = REF_NONE; tr.sp = st.sp_init(tid); tr.sb = 0; tr.t = 0; tr.idx = 0; tr.u = tr.v = 0; tr.pf0 = tr.pf1 = 0;
+    tr.cur = REF_NONE; tr.sp = st.sp_init(tid); tr.sb = 0; tr.t = 0; tr.idx = 0; tr.u = tr.v = 0;
     tr.ray = Ray{0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t out_index = 0;
     uint32_t nbox = 0, ntri = 0;
@@ -875,7 +854,6 @@ __global__ void __launch_bounds__(BLOCK) k_static(const SceneDev s, const JobPar
     const uint32_t item = blockIdx.x * (BLOCK / 64) + (tid >> 6);
     if (item >= p.n_items) return;
     Trav tr;
-    tr.pf0 = tr.pf1 = 0;
     uint32_t nbox = 0, ntri = 0;
     if (MODE == MODE_TRACE) {
         const uint64_t ri = (uint64_t)item * 64u + lane;
