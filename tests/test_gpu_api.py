@@ -381,6 +381,36 @@ def test_frames_in_flight_on_several_streams(tracer, atrium):
         tracer.set_stream(None)
 
 
+def test_two_contexts_render_concurrently(tracer, atrium):
+    """Two contexts of one process on the same GPU (each with its own scene copy and launch scratch),
+    frames issued alternately on streams of their own: every frame equals the one rendered alone."""
+    import torch
+    sc, camera, tex = atrium
+    W, H = 480, 270
+    inv = camera.inv_proj_view()
+    dev = torch.device("cuda", 0)
+    tracer.upload_scene(sc)
+    tracer.upload_texture(0, tex[0]); tracer.upload_texture(1, tex[1])
+    alone = tracer.render(W, H, camera=(inv, camera.position), has_tex_coords=1, has_normals=1)["rgba"]
+    other = HipRayTracer(0)
+    try:
+        other.upload_scene(sc)
+        other.upload_texture(0, tex[0]); other.upload_texture(1, tex[1])
+        ctxs = (tracer, other)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+        outs = [torch.zeros((W * H, 4), dtype=torch.float32, device=dev) for _ in range(4)]
+        for k in range(24):
+            c = ctxs[k % 2]
+            c.set_stream(streams[k % 4].cuda_stream)
+            c.render_device(W, H, camera=(inv, camera.position), has_tex_coords=True, has_normals=True, rgba_ptr=outs[k % 4].data_ptr())
+        torch.cuda.synchronize()
+        for o in outs:
+            assert np.array_equal(bits(o.cpu().numpy()), bits(alone))
+    finally:
+        tracer.set_stream(None)
+        other.close()
+
+
 @pytest.mark.timeout(900)
 def test_full_size_soup_10m_4k(tracer, oracle_a):
     """BASELINE config 4 at full size: 10 000 000-triangle soup (seed 1, no uvs / normals), 3840x2160,
