@@ -2,7 +2,8 @@
 """Kernel A/B bench (GPU box): one workload, many (library build, option) arms,
 interleaved rounds in one process per library, kernel time from HIP events.
 Usage: tools/kbench.py [--workload W] [--rounds N] arm [arm ...]
-  arm = name[:key=value[,key=value...]]   keys: variant, dyn_thresh, num_queues, mode(fused|trace|incoherent)
+  arm = name[:key=value[,key=value...]]   keys: variant, dyn_thresh, num_queues, leaf_thresh, queue_stride, queue_block,
+        blocks (max_blocks_per_cu), anyhit, mode(fused|trace|incoherent)
 Libraries: RTAMD_DEVICE_LIB env (one process = one library)."""
 import argparse
 import json
