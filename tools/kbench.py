@@ -91,6 +91,7 @@ def main():
             ms = tr.last_kernel_ms()
             if r >= 2:
                 res[name].append(ms)
+            coh[name] = tr.last_launch_coherence() if int(o.get("variant", 0)) == 0 else (-1.0, -1.0, 0)
     lib = os.environ.get("RTAMD_DEVICE_LIB", "default")
     for name, _ in arms:
         v = np.array(res[name])
