@@ -217,3 +217,24 @@ def test_subdivide_counts():
     t2, p2, n2 = scenes.subdivide(tri, g["positions"], g["normals"], levels=2)
     assert len(t2) == 16 * len(tri) == 80016 and len(p2) == len(n2)
     assert np.allclose(np.linalg.norm(n2, axis=1), 1, atol=1e-5)
+
+
+def test_unorm8_conversion_formula_is_exact_division():
+    """rt_kernels.hip unorm8_to_float: q = x * fl(1/255); q + fma(-q, 255, x) * fl(1/255), both steps fused,
+    equals the correctly rounded x / 255 of the texture unit for all 256 inputs (exact rational arithmetic)."""
+    from fractions import Fraction
+
+    def rnd(fr):
+        if fr == 0:
+            return np.float32(0)
+        f = np.float32(float(fr))
+        cands = [np.nextafter(f, np.float32(-np.inf)), f, np.nextafter(f, np.float32(np.inf))]
+        return np.float32(min(cands, key=lambda v: (abs(Fraction(float(v)) - fr), int(np.float32(v).view(np.uint32)) & 1)))
+
+    r = np.float32(1.0) / np.float32(255.0)
+    for xi in range(256):
+        x = np.float32(xi)
+        q = x * r
+        e = rnd(Fraction(float(x)) - Fraction(float(q)) * 255)
+        q2 = rnd(Fraction(float(q)) + Fraction(float(e)) * Fraction(float(r)))
+        assert q2 == x / np.float32(255.0), xi
