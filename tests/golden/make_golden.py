@@ -15,7 +15,10 @@ inputs + outputs as compressed .npz files:
            material bits / 1e30 "no surface") derived from the bunny frame, a seeded 64x64
            unit-vector noise texture -> b_org, b_shadow_dir, b_reflect_dir, b_ambient_dir
 
-The fixtures are data only.  Usage:  python tests/golden/make_golden.py
+  golden_atrium.npz: the two shaders' outputs for the procedural headline scene (262 944 triangles, 240x135);
+           the scene itself is rebuilt by the test (deterministic) and pinned by a digest
+
+The fixtures are data only.  Usage:  python tests/golden/make_golden.py [--only-atrium]
 """
 import math
 import os
@@ -158,5 +161,35 @@ def main():
     print("special:", int((b_trace[..., 0] < 1e30).sum()), "hits of", hh * ww)
 
 
+def atrium():
+    """The headline scene (bench.py's atrium_1080p, BASELINE config 3) at 240x135: the scene is procedural and
+    deterministic (raytracer_amd/scenes.py + the host BVH builder), so only the shader outputs are stored; the
+    test rebuilds the scene and also checks a digest of its arrays."""
+    import hashlib
+    from raytracer_amd import scenes
+    B = OracleB()
+    w, h = 240, 135
+    tri, pos, uv, nrm, cam = scenes.atrium()
+    m = host.Model.from_arrays(tri, pos, uv, nrm)
+    m.build_bvh()
+    sc = m.scene_arrays()
+    d = np.asarray(cam["direction"], np.float32)
+    d /= np.linalg.norm(d)
+    camera = host.Camera(16 / 9, fov=math.radians(cam["fov_deg"]), position=cam["position"], direction=d)
+    dirs, orgs = camera.primary_rays(w, h)
+    tex0, tex1 = scenes.checker_texture(), scenes.noise_texture()
+    b_trace, _ = B.trace(sc, dirs, orgs)
+    b_fused, _ = B.fused(sc, dirs, orgs, True, True, tex0, tex1)
+    digest = hashlib.sha256(b"".join(np.ascontiguousarray(sc[k]).tobytes() for k in ("nodes", "triangles", "positions", "tex_coords", "normals"))).hexdigest()
+    path = os.path.join(HERE, "golden_atrium.npz")
+    np.savez_compressed(path, width=np.int32(w), height=np.int32(h), b_trace=b_trace, b_fused=b_fused, scene_sha256=np.array(digest),
+                        renderer=np.array(B.renderer))
+    print(f"atrium: {len(sc['triangles'])} tris, {int((b_trace[..., 0] < 1e30).sum())}/{w * h} hit pixels -> {os.path.getsize(path) / 1e6:.2f} MB")
+
+
 if __name__ == "__main__":
-    main()
+    if "--only-atrium" in sys.argv:
+        atrium()
+    else:
+        main()
+        atrium()

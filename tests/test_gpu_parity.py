@@ -77,6 +77,29 @@ def test_fused_render_matches_reference_shader(tracer, oracle_a, name, variant, 
     assert np.all(r["rgba"][:, 3] == 1.0)
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+def test_headline_scene_matches_reference_shaders(tracer, variant):
+    """bench.py's scene against the llvmpipe fixture (tests/golden/golden_atrium.npz): trace records and the fused
+    shader's hit buffers bit-exact, colour <= 1/255 outside mixed-material 4x4 blocks."""
+    from common import atrium_golden
+    g = atrium_golden()
+    w, h = g["w"], g["h"]
+    tracer.upload_scene(g["scene"])
+    tracer.upload_texture(0, g["tex0"]); tracer.upload_texture(1, g["tex1"])
+    try:
+        tracer.set_kernel_variant(variant)
+        t = tracer.trace(g["org"].reshape(-1, 3), g["dir"].reshape(-1, 3))
+        r = tracer.render(w, h, dir=g["dir"], org=g["org"], has_tex_coords=1, has_normals=1)
+    finally:
+        tracer.set_kernel_variant(0)
+    assert np.array_equal(bits(t), bits(g["b_trace"]))
+    hit = r["hit_id"] != 0xFFFFFFFF
+    assert np.array_equal(hit, g["b_trace"][:, 0] < 1000.0)
+    assert np.array_equal(r["hit_id"][hit], bits(g["b_trace"][:, 3])[hit]) and np.array_equal(bits(r["hit_t"])[hit], bits(g["b_trace"][:, 0])[hit])
+    mixed = mixed_material_mask(r["hit_id"], g["scene"]["triangles"]["mat_idx"], h, w)
+    assert rgb_err_255(r["rgba"], g["b_fused"])[~mixed].max() <= 1.0
+
+
 def test_ray_dispatcher_matches_reference_shader(tracer, oracle_a):
     """k_dispatch_rays vs ray_dispatcher.frag on llvmpipe (fixture) and vs oracle A, through the host
     entry point; then ragged sizes (partial last block, sizes below one block) vs oracle A bit for bit."""
