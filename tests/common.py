@@ -88,3 +88,23 @@ def atrium_golden():
     dirs, orgs = camera.primary_rays(w, h)
     return {"scene": sc, "dir": dirs, "org": orgs, "tex0": scenes.checker_texture(), "tex1": scenes.noise_texture(),
             "b_trace": g["b_trace"].reshape(-1, 4), "b_fused": g["b_fused"].reshape(-1, 4), "w": w, "h": h}
+
+
+def soup_golden():
+    """BASELINE config 4's kind of scene at fixture size (tests/golden/golden_soup.npz, make_golden.py:soup):
+    dict(scene, dir, org, rand_org, rand_dir, b_trace, b_fused, b_trace_rand, w, h)."""
+    import hashlib
+    import math
+    from raytracer_amd import host, scenes
+    g = load_golden("soup")
+    w, h = int(g["width"]), int(g["height"])
+    tri, pos, cam = scenes.triangle_soup(100_000, seed=3, extent=12.0, size=0.5)
+    m = host.Model.from_arrays(tri, pos)
+    m.build_bvh()
+    sc = m.scene_arrays()
+    digest = hashlib.sha256(b"".join(np.ascontiguousarray(sc[k]).tobytes() for k in ("nodes", "triangles", "positions"))).hexdigest()
+    assert digest == str(g["scene_sha256"]), "the rebuilt soup differs from the one the fixture was made with"
+    camera = host.Camera(w / h, fov=math.radians(cam["fov_deg"]), position=cam["position"], direction=cam["direction"])
+    dirs, orgs = camera.primary_rays(w, h)
+    return {"scene": sc, "dir": dirs, "org": orgs, "rand_org": g["rand_org"].reshape(-1, 3), "rand_dir": g["rand_dir"].reshape(-1, 3),
+            "b_trace": g["b_trace"].reshape(-1, 4), "b_fused": g["b_fused"].reshape(-1, 4), "b_trace_rand": g["b_trace_rand"].reshape(-1, 4), "w": w, "h": h}

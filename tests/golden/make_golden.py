@@ -18,7 +18,9 @@ inputs + outputs as compressed .npz files:
   golden_atrium.npz: the two shaders' outputs for the procedural headline scene (262 944 triangles, 240x135);
            the scene itself is rebuilt by the test (deterministic) and pinned by a digest
 
-The fixtures are data only.  Usage:  python tests/golden/make_golden.py [--only-atrium]
+  golden_soup.npz: the same for a 100 000-triangle seeded soup (camera frame + 8192 random rays)
+
+The fixtures are data only.  Usage:  python tests/golden/make_golden.py [--only-atrium | --only-soup]
 """
 import math
 import os
@@ -187,9 +189,37 @@ def atrium():
     print(f"atrium: {len(sc['triangles'])} tris, {int((b_trace[..., 0] < 1e30).sum())}/{w * h} hit pixels -> {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def soup():
+    """BASELINE config 4's kind of scene at fixture size: 100 000-triangle seeded soup (dense enough that most
+    rays hit: extent 12, size 0.5), camera frame 200x150 plus 8192 random rays with NO_RAY entries; outputs only."""
+    import hashlib
+    from raytracer_amd import scenes
+    B = OracleB()
+    w, h = 200, 150
+    tri, pos, cam = scenes.triangle_soup(100_000, seed=3, extent=12.0, size=0.5)
+    m = host.Model.from_arrays(tri, pos)
+    m.build_bvh()
+    sc = m.scene_arrays()
+    camera = host.Camera(w / h, fov=math.radians(cam["fov_deg"]), position=cam["position"], direction=cam["direction"])
+    dirs, orgs = camera.primary_rays(w, h)
+    b_trace, _ = B.trace(sc, dirs, orgs)
+    b_fused, _ = B.fused(sc, dirs, orgs, False, False, None, None)
+    ro, rd = random_rays(sc["positions"], 8192, seed=77)
+    b_rand, _ = B.trace(sc, rd, ro)
+    digest = hashlib.sha256(b"".join(np.ascontiguousarray(sc[k]).tobytes() for k in ("nodes", "triangles", "positions"))).hexdigest()
+    path = os.path.join(HERE, "golden_soup.npz")
+    np.savez_compressed(path, width=np.int32(w), height=np.int32(h), b_trace=b_trace, b_fused=b_fused, rand_org=ro, rand_dir=rd, b_trace_rand=b_rand,
+                        scene_sha256=np.array(digest), renderer=np.array(B.renderer))
+    print(f"soup: {len(sc['triangles'])} tris, {int((b_trace[..., 0] < 1e30).sum())}/{w * h} hit pixels, "
+          f"{int((b_rand[..., 0] < 1e30).sum())}/8192 random hits -> {os.path.getsize(path) / 1e6:.2f} MB")
+
+
 if __name__ == "__main__":
     if "--only-atrium" in sys.argv:
         atrium()
+    elif "--only-soup" in sys.argv:
+        soup()
     else:
         main()
         atrium()
+        soup()

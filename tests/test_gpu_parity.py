@@ -100,6 +100,26 @@ def test_headline_scene_matches_reference_shaders(tracer, variant):
     assert rgb_err_255(r["rgba"], g["b_fused"])[~mixed].max() <= 1.0
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+def test_triangle_soup_matches_reference_shaders(tracer, variant):
+    """tests/golden/golden_soup.npz: 100 000-triangle soup, camera frame + 8192 random rays against llvmpipe."""
+    from common import soup_golden
+    g = soup_golden()
+    tracer.upload_scene(g["scene"])
+    white = np.full((1, 1, 3), 255, np.uint8)
+    tracer.upload_texture(0, white); tracer.upload_texture(1, white)
+    try:
+        tracer.set_kernel_variant(variant)
+        assert np.array_equal(bits(tracer.trace(g["org"].reshape(-1, 3), g["dir"].reshape(-1, 3))), bits(g["b_trace"]))
+        assert np.array_equal(bits(tracer.trace(g["rand_org"], g["rand_dir"])), bits(g["b_trace_rand"]))
+        r = tracer.render(g["w"], g["h"], dir=g["dir"], org=g["org"], has_tex_coords=0, has_normals=0)
+    finally:
+        tracer.set_kernel_variant(0)
+    hit = r["hit_id"] != 0xFFFFFFFF
+    assert np.array_equal(hit, g["b_trace"][:, 0] < 1000.0) and np.array_equal(r["hit_id"][hit], bits(g["b_trace"][:, 3])[hit])
+    assert rgb_err_255(r["rgba"], g["b_fused"]).max() < 0.01
+
+
 def test_ray_dispatcher_matches_reference_shader(tracer, oracle_a):
     """k_dispatch_rays vs ray_dispatcher.frag on llvmpipe (fixture) and vs oracle A, through the host
     entry point; then ragged sizes (partial last block, sizes below one block) vs oracle A bit for bit."""
