@@ -108,3 +108,17 @@ def soup_golden():
     dirs, orgs = camera.primary_rays(w, h)
     return {"scene": sc, "dir": dirs, "org": orgs, "rand_org": g["rand_org"].reshape(-1, 3), "rand_dir": g["rand_dir"].reshape(-1, 3),
             "b_trace": g["b_trace"].reshape(-1, 4), "b_fused": g["b_fused"].reshape(-1, 4), "b_trace_rand": g["b_trace_rand"].reshape(-1, 4), "w": w, "h": h}
+
+
+def check_raycreate(generate):
+    """generate(w, h, inv_proj_view16, near, far) -> (h*w, 3) directions, checked against the llvmpipe runs of
+    ray_trace/ray_create.frag in tests/golden/golden_raycreate.npz: the shader uses the rasteriser's interpolated
+    fragPos, so 95+ % of the components are bit-equal and the rest within 2e-5."""
+    g = load_golden("raycreate")
+    near, far = (float(x) for x in g["near_far"])
+    for k in range(int(g["count"])):
+        w, h = (int(x) for x in g[f"size{k}"])
+        want = g[f"b_dir{k}"].reshape(-1, 3)
+        got = np.asarray(generate(w, h, g[f"inv_proj_view{k}"], near, far), np.float32).reshape(-1, 3)
+        assert np.abs(got - want).max() <= 2e-5, (k, float(np.abs(got - want).max()))
+        assert (bits(got) == bits(want)).mean() >= 0.95, k

@@ -18,9 +18,10 @@ inputs + outputs as compressed .npz files:
   golden_atrium.npz: the two shaders' outputs for the procedural headline scene (262 944 triangles, 240x135);
            the scene itself is rebuilt by the test (deterministic) and pinned by a digest
 
-  golden_soup.npz: the same for a 100 000-triangle seeded soup (camera frame + 8192 random rays)
+  golden_raycreate.npz: ray_trace/ray_create.frag for three cameras (inputs + RGB32F direction target)
+  golden_soup.npz: the same as golden_atrium for a 100 000-triangle seeded soup (camera frame + 8192 random rays)
 
-The fixtures are data only.  Usage:  python tests/golden/make_golden.py [--only-atrium | --only-soup]
+The fixtures are data only.  Usage:  python tests/golden/make_golden.py [--only-atrium | --only-soup | --only-raycreate]
 """
 import math
 import os
@@ -214,8 +215,30 @@ def soup():
           f"{int((b_rand[..., 0] < 1e30).sum())}/8192 random hits -> {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def raycreate():
+    """ray_trace/ray_create.frag on llvmpipe for three cameras: inputs (inverse proj*view, near, far) and the RGB32F
+    direction target.  The shader works on the rasteriser's interpolated fragPos, ours on pixel centres computed in
+    float: 96-100 % of the components are bit-equal, the rest within 1.5e-5 (tests use 2e-5)."""
+    B = OracleB()
+    out = {}
+    cams = [(240, 135, (0.5, 1.5, -2.0), (0.2, -0.1, 0.97), 75.0), (160, 120, (3.0, 4.0, 5.0), (-0.5, -0.4, -0.6), 120.0), (64, 64, (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 30.0)]
+    for k, (w, h, pos, d, fov) in enumerate(cams):
+        dd = np.asarray(d, np.float32)
+        dd /= np.linalg.norm(dd)
+        cam = host.Camera(w / h, fov=math.radians(fov), position=pos, direction=dd)
+        inv = np.asarray(cam.inv_proj_view(), np.float32).reshape(16)
+        b = np.asarray(B.raycreate(w, h, inv, host.NEAR, host.FAR), np.float32).reshape(h, w, -1)[..., :3]
+        out[f"size{k}"] = np.int32([w, h]); out[f"inv_proj_view{k}"] = inv; out[f"b_dir{k}"] = np.ascontiguousarray(b)
+    out["near_far"] = np.float32([host.NEAR, host.FAR]); out["count"] = np.int32(len(cams)); out["renderer"] = np.array(B.renderer)
+    path = os.path.join(HERE, "golden_raycreate.npz")
+    np.savez_compressed(path, **out)
+    print("raycreate:", len(cams), "cameras ->", os.path.getsize(path) / 1e6, "MB")
+
+
 if __name__ == "__main__":
-    if "--only-atrium" in sys.argv:
+    if "--only-raycreate" in sys.argv:
+        raycreate()
+    elif "--only-atrium" in sys.argv:
         atrium()
     elif "--only-soup" in sys.argv:
         soup()
@@ -223,3 +246,4 @@ if __name__ == "__main__":
         main()
         atrium()
         soup()
+        raycreate()

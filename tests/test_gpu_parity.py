@@ -120,6 +120,16 @@ def test_triangle_soup_matches_reference_shaders(tracer, variant):
     assert rgb_err_255(r["rgba"], g["b_fused"]).max() < 0.01
 
 
+def test_ray_creation_matches_reference_shader(tracer):
+    """rtamd_generate_rays against the llvmpipe runs of ray_create.frag (three cameras)."""
+    from common import check_raycreate
+    from raytracer_amd import host
+    def gen(w, h, inv, near, far):
+        assert (near, far) == (host.NEAR, host.FAR)
+        return tracer.generate_rays(w, h, inv)
+    check_raycreate(gen)
+
+
 def test_ray_dispatcher_matches_reference_shader(tracer, oracle_a):
     """k_dispatch_rays vs ray_dispatcher.frag on llvmpipe (fixture) and vs oracle A, through the host
     entry point; then ragged sizes (partial last block, sizes below one block) vs oracle A bit for bit."""
