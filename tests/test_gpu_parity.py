@@ -125,7 +125,7 @@ def test_ray_creation_matches_reference_shader(tracer):
     from common import check_raycreate
     from raytracer_amd import host
     def gen(w, h, inv, near, far):
-        assert (near, far) == (host.NEAR, host.FAR)
+        assert (np.float32(near), np.float32(far)) == (np.float32(host.NEAR), np.float32(host.FAR))
         return tracer.generate_rays(w, h, inv)
     check_raycreate(gen)
 
