@@ -94,8 +94,8 @@ def build_workload(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="atrium_1080p")
     ap.add_argument("--variant", type=int, default=0, help="0 persistent (default), 1 static A/B baseline")
     ap.add_argument("--frames-in-flight", type=int, default=0,
