@@ -19,6 +19,19 @@ __global__ void k(float *out, int iters) {
                 else if (OP == 5) a[i] = (a[i] < b) ? a[(i + 1) & 7] : c;            // v_cmp + v_cndmask
                 else if (OP == 6) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 7]));
             }
+            if (OP >= 10) {   // integer classes on the same 8 chains (bit patterns of the floats)
+                unsigned *u = reinterpret_cast<unsigned *>(a);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (OP == 10) asm volatile("v_add_u32 %0, %1, %2" : "=v"(u[i]) : "v"(u[i]), "v"(u[(i + 1) & 7]));
+                    else if (OP == 11) asm volatile("v_and_b32 %0, %1, %2" : "=v"(u[i]) : "v"(u[i]), "v"(u[(i + 1) & 7]));
+                    else if (OP == 12) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(u[i]) : "v"(u[i]), "v"(u[(i + 1) & 7]));
+                    else if (OP == 13) asm volatile("v_lshlrev_b32 %0, 1, %1" : "=v"(u[i]) : "v"(u[i]));
+                    else if (OP == 14) asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_cmp_lt_f32 vcc, %2, %1" : "=v"(u[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]), "0"(u[i]) : "vcc");
+                    else if (OP == 15) asm volatile("v_sub_f32 %0, %1, %2\n\tv_max_f32 %0, %0, %2" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]));
+                    else if (OP == 16) asm volatile("v_sub_f32 %0, %1, %2\n\tv_mul_f32 %0, %0, %2\n\tv_max_f32 %0, %0, %2" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 1) & 7]));
+                }
+            } else
             if (OP >= 7) {   // packed fp32: 4 chains of float2 (two results per instruction)
                 typedef float f2 __attribute__((ext_vector_type(2)));
                 f2 *p = reinterpret_cast<f2 *>(a);
@@ -52,5 +65,7 @@ int main() {
     run<0>("v_mul_f32", out, 128); run<1>("v_sub_f32", out, 128); run<2>("v_min/max_f32", out, 128); run<3>("mul,sub,min,max mix", out, 128);
     run<4>("v_max3_f32", out, 128); run<5>("v_cmp + v_cndmask (2 instr)", out, 256); run<6>("v_mov_b32", out, 128);
     run<7>("v_pk_mul_f32 (2 results)", out, 64); run<8>("v_pk_add_f32 (2 results)", out, 64); run<9>("v_pk_add_f32 neg+op_sel", out, 64);
+    run<10>("v_add_u32", out, 128); run<11>("v_and_b32", out, 128); run<12>("v_xor_b32", out, 128); run<13>("v_lshlrev_b32", out, 128);
+    run<14>("v_cmp_lt_f32 x2 (no cndmask)", out, 256); run<15>("v_sub + v_max (1 fast : 1 slow)", out, 256); run<16>("v_sub + v_mul + v_max (2 fast : 1 slow)", out, 384);
     return 0;
 }
