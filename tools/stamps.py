@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU box): wave lifetime histogram of k_persistent from the
--DRTAMD_EXP_STAMPS build.  RTAMD_DEVICE_LIB must point at that build."""
+-DRTAMD_EXP_STAMPS build.  RTAMD_DEVICE_LIB must point at that build:
+    hipcc <HIP_FLAGS of raytracer_amd/csrc/Makefile> -DRTAMD_EXP_STAMPS -Iinclude -shared \
+          -o raytracer_amd/lib/exp_stamps.so raytracer_amd/csrc/device/rtamd_api.hip
+    RTAMD_DEVICE_LIB=$PWD/raytracer_amd/lib/exp_stamps.so python tools/stamps.py [workload]
+The per-item records hold 65 536 items (a 1080p frame has 32 400): use it on 1080p workloads."""
 import ctypes, os, sys
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
