@@ -51,6 +51,11 @@ typedef struct rtamd_context rtamd_context;
 /* Value written to hit_id outputs for pixels whose primary ray misses
  * (the fused shader leaves triangleIdx at its initial 0 and shades the sky,
  * ray_trace_and_shade.frag:201,232-234). */
+/* Bumped whenever a struct layout or the meaning of an argument changes; a binder compares its compile-time
+ * value with rtamd_abi_version() of the library it loaded.  (No counterpart in the reference.) */
+#define RTAMD_ABI_VERSION 3
+uint32_t rtamd_abi_version(void);
+
 #define RTAMD_NO_HIT 0xFFFFFFFFu
 
 /* Framebuffer tile used to shard a frame over ranks (interleaved tiles, scene

@@ -136,6 +136,9 @@ def host_lib():
     return _host
 
 
+ABI_VERSION = 3   # include/rtamd.h RTAMD_ABI_VERSION
+
+
 def device_lib():
     global _device
     if _device is None:
@@ -152,6 +155,9 @@ def device_lib():
             except ImportError:
                 pass
         L = ctypes.CDLL(DEVICE_LIB_PATH)
+        L.rtamd_abi_version.restype = ctypes.c_uint32
+        if L.rtamd_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{DEVICE_LIB_PATH} has ABI version {L.rtamd_abi_version()}, these bindings are for {ABI_VERSION}: rebuild the library")
         vp = ctypes.c_void_p
         L.rtamd_context_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
         L.rtamd_context_create.restype = ctypes.c_int

@@ -923,6 +923,8 @@ int rtamd_assemble_tiles_device(rtamd_context *ctx, const void *gathered, uint32
     return rtamd_assemble_tile_batch_device(ctx, gathered, width, height, tile_world, elems_per_pixel, 1, frame_out);
 }
 
+uint32_t rtamd_abi_version(void) { return RTAMD_ABI_VERSION; }
+
 int rtamd_get_scene_info(const rtamd_context *ctx, rtamd_scene_info *info) {
     if (!ctx || !info) return RTAMD_ERR_INVALID_ARGUMENT;
     if (!ctx->has_scene) return RTAMD_ERR_NO_SCENE;

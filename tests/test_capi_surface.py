@@ -66,3 +66,13 @@ def test_product_never_references_the_oracle():
                     if re.search(r"oracle_a|liboracle|glsl_ref|from oracle|import oracle|oracles", text):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_abi_version_of_header_library_and_bindings_agree():
+    import re
+    from raytracer_amd import _ffi
+    hdr = open(os.path.join(REPO, "include", "rtamd.h")).read()
+    v = int(re.search(r"#define RTAMD_ABI_VERSION (\d+)", hdr).group(1))
+    lib = ctypes.CDLL(_ffi.DEVICE_LIB_PATH)
+    lib.rtamd_abi_version.restype = ctypes.c_uint32
+    assert v == _ffi.ABI_VERSION == lib.rtamd_abi_version()
