@@ -103,6 +103,9 @@ def main():
                          "several GPUs, where a launch covers 1/N of the frame and is bounded by its slowest rays, not by throughput)")
     ap.add_argument("--gather-batch", type=int, default=0,
                     help="N > 1: frames per RCCL gather (0 = auto: 4 up to 1080p, 1 above)")
+    ap.add_argument("--gather-format", choices=("f32", "rgba8"), default="f32",
+                    help="N > 1: what crosses xGMI. f32 = the shader's RGBA32F target (default, like the reference's float "
+                         "framebuffers); rgba8 = the display pass's 8-bit back buffer (util/display.frag), a quarter of the bytes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -193,9 +196,17 @@ def main():
         render_streams[1] = min(candidates, key=pair_ms)
         tracer.set_stream(stream.cuda_stream)
     frame = None
+    as8 = world > 1 and args.gather_format == "rgba8"
+    send = rgba
+    if as8:   # each rank converts its share with the display pass; the gather moves packed RGBA8
+        send = [torch.zeros((G * n_local_out,), dtype=torch.int32, device=dev) for _ in range(F)]
     if world > 1 and rank == 0:
-        gathered = torch.empty((world, G * n_local_out, 4), dtype=torch.float32, device=dev)   # [rank][frame of the batch][pixel]
-        frames_out = torch.empty((G, n_px, 4), dtype=torch.float32, device=dev)
+        if as8:
+            gathered = torch.empty((world, G * n_local_out), dtype=torch.int32, device=dev)
+            frames_out = torch.empty((G, n_px), dtype=torch.int32, device=dev)
+        else:
+            gathered = torch.empty((world, G * n_local_out, 4), dtype=torch.float32, device=dev)   # [rank][frame of the batch][pixel]
+            frames_out = torch.empty((G, n_px, 4), dtype=torch.float32, device=dev)
         frame = frames_out[0]
     launch_events = []
     pending = [None]   # batch buffer that holds rendered frames not gathered yet
@@ -207,18 +218,18 @@ def main():
             stream.wait_stream(rs)
         if rehearse:
             stream.synchronize()
-            mine = rgba[f].cpu()
+            mine = send[f].cpu()
             parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
             dist.gather(mine, gather_list=parts, dst=0)
             if rank == 0:
                 gathered.copy_(torch.stack(parts))
         elif rank == 0:
-            dist.gather(rgba[f], gather_list=list(gathered.unbind(0)), dst=0)
+            dist.gather(send[f], gather_list=list(gathered.unbind(0)), dst=0)
         else:
-            dist.gather(rgba[f], dst=0)
+            dist.gather(send[f], dst=0)
         if rank == 0:
             tracer.set_stream(stream.cuda_stream)
-            tracer.assemble_tile_batch_device(gathered.data_ptr(), W, H, world, 4, G, frames_out.data_ptr())
+            tracer.assemble_tile_batch_device(gathered.data_ptr(), W, H, world, 1 if as8 else 4, G, frames_out.data_ptr())
         consumed[f].record(stream)
         pending[0] = None
 
@@ -240,6 +251,8 @@ def main():
         if timed:
             e1.record(rs)
             launch_events.append((e0, e1))
+        if as8:
+            tracer.display_rgba8_device(rgba[f].data_ptr() + g * n_local_out * 16, n_local_out, send[f].data_ptr() + g * n_local_out * 4)
         if world > 1:
             pending[0] = f
             if g == G - 1:
@@ -321,7 +334,12 @@ def main():
         tracer.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=has_tc, has_normals=has_n, rgba_ptr=full.data_ptr())
         torch.cuda.synchronize()
         n_last = (args.steps - 1) % G + 1      # frames the last gathered batch holds
-        frame_check = all(bool(torch.equal(full.view(torch.int32), frames_out[i].view(torch.int32))) for i in range(n_last))
+        if as8:
+            full8 = torch.zeros((n_px,), dtype=torch.int32, device=dev)
+            tracer.display_rgba8_device(full.data_ptr(), n_px, full8.data_ptr())
+            torch.cuda.synchronize()
+            full = full8
+        frame_check = all(bool(torch.equal(full.view(torch.int32).reshape(-1), frames_out[i].view(torch.int32).reshape(-1))) for i in range(n_last))
 
     ms_per_step = elapsed * 1e3 / args.steps
     value = rays_per_frame * args.steps / elapsed / 1e6
@@ -344,7 +362,7 @@ def main():
                                f"{W}x{H}, 1 spp, primary + sun shadow ray + shading (fused ray_trace_and_shade semantics)",
                    "rays_per_frame": rays_per_frame, "primary_rays": n_primary_all, "shadow_rays": n_shadow_all,
                    "parallelism": f"tiles{world}" if world > 1 else "single", "kernel_variant": args.variant,
-                   "frames_in_flight": F, **({"frames_per_gather": G} if world > 1 else {}), "shadow_rays_stop_at_first_occluder": True,
+                   "frames_in_flight": F, **({"frames_per_gather": G, "gather_format": args.gather_format} if world > 1 else {}), "shadow_rays_stop_at_first_occluder": True,
                    **({"assembled_frame_equals_single_gpu_frame": frame_check} if frame_check is not None else {}),
                    **({"REHEARSAL_not_a_measurement": "all ranks on cuda:0, gloo gather through host memory"} if rehearse else {}),
                    "bvh_build_s": round(build_s, 2)},

@@ -278,6 +278,15 @@ int rtamd_assemble_tiles_device(rtamd_context *ctx, const void *gathered, uint32
 int rtamd_assemble_tile_batch_device(rtamd_context *ctx, const void *gathered, uint32_t width, uint32_t height,
                                      uint32_t tile_world, uint32_t elems_per_pixel, uint32_t n_frames, void *frames_out);
 
+/* ---- display pass: util/display.frag:9 ------------------------------------------ */
+
+/* The reference's last pass copies the float colour target to the window's 8-bit back buffer
+ * (src/main.rs:232-238, util/display.frag:9); the conversion is OpenGL's float -> unorm8 (clamp to
+ * [0,1], x255, round to nearest).  This is that conversion for n_pixels RGBA32F pixels (any layout:
+ * scan-line frame or compact tiles) into packed RGBA8 (R in the low byte): a frame then leaves the
+ * GPU, or crosses xGMI, at a quarter of the bytes.  NaN converts to 0.  Device pointers. */
+int rtamd_display_rgba8_device(rtamd_context *ctx, const float *rgba32f, uint64_t n_pixels, uint32_t *rgba8_out);
+
 /* ---- introspection ---------------------------------------------------------- */
 
 typedef struct rtamd_scene_info {

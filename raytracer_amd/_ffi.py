@@ -203,6 +203,8 @@ def device_lib():
         L.rtamd_assemble_tiles_device.restype = ctypes.c_int
         L.rtamd_assemble_tile_batch_device.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp]
         L.rtamd_assemble_tile_batch_device.restype = ctypes.c_int
+        L.rtamd_display_rgba8_device.argtypes = [vp, vp, ctypes.c_uint64, vp]
+        L.rtamd_display_rgba8_device.restype = ctypes.c_int
         L.rtamd_get_scene_info.argtypes = [vp, ctypes.POINTER(SceneInfo)]
         L.rtamd_get_scene_info.restype = ctypes.c_int
         L.rtamd_last_kernel_ms.argtypes = [vp, c_float_p]

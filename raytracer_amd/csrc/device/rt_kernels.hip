@@ -1057,4 +1057,17 @@ __global__ void k_assemble_tiles(const uint32_t *__restrict__ gathered, uint32_t
     for (uint32_t e = 0; e < elems; e++) out[dst * elems + e] = gathered[src * elems + e];
 }
 
+// util/display.frag:9 writes the float colour target to the window's 8-bit back buffer; the conversion is the
+// GL one (4.6 spec 2.3.5: clamp to [0,1], x255, round to nearest; NaN -> 0 here).  HBM stream: 16 B in, 4 B out.
+__device__ __forceinline__ uint32_t to_unorm8(float x) {
+    x = (x == x) ? fminf(fmaxf(x, 0.0f), 1.0f) : 0.0f;
+    return (uint32_t)__builtin_rintf(x * 255.0f);
+}
+__global__ void k_display_rgba8(const float4 *__restrict__ rgba, uint64_t n, uint32_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = rgba[i];
+    out[i] = to_unorm8(c.x) | (to_unorm8(c.y) << 8) | (to_unorm8(c.z) << 16) | (to_unorm8(c.w) << 24);
+}
+
 }  // namespace rtamd

@@ -923,6 +923,18 @@ int rtamd_assemble_tiles_device(rtamd_context *ctx, const void *gathered, uint32
     return rtamd_assemble_tile_batch_device(ctx, gathered, width, height, tile_world, elems_per_pixel, 1, frame_out);
 }
 
+int rtamd_display_rgba8_device(rtamd_context *ctx, const float *rgba32f, uint64_t n_pixels, uint32_t *rgba8_out) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (n_pixels == 0) return RTAMD_OK;
+    if (!rgba32f || !rgba8_out || n_pixels > 0x7FFFFFFFull * 256ull) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "bad display arguments");
+    if ((uintptr_t)rgba32f & 15u) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "rgba32f must be 16-byte aligned");
+    int rc = ensure_ctx_device(ctx);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_display_rgba8, dim3((uint32_t)((n_pixels + 255) / 256)), dim3(256), 0, ctx->stream, (const float4 *)rgba32f, n_pixels, rgba8_out);
+    HIP_TRY(ctx, hipGetLastError());
+    return RTAMD_OK;
+}
+
 uint32_t rtamd_abi_version(void) { return RTAMD_ABI_VERSION; }
 
 int rtamd_get_scene_info(const rtamd_context *ctx, rtamd_scene_info *info) {

@@ -266,6 +266,10 @@ class HipRayTracer:
                                                           elems_per_pixel, ctypes.c_void_p(frame_ptr)))
 
 
+    def display_rgba8_device(self, rgba_ptr, n_pixels, out_ptr):
+        """util/display.frag: RGBA32F -> packed RGBA8 (GL unorm conversion) on the device."""
+        self._check(self._lib.rtamd_display_rgba8_device(self._h, ctypes.c_void_p(rgba_ptr), int(n_pixels), ctypes.c_void_p(out_ptr)))
+
     def assemble_tile_batch_device(self, gathered_ptr, width, height, tile_world, elems_per_pixel, n_frames, frames_ptr):
         """gathered [rank][frame][tiles_per_rank*1024 px] -> frames [frame][height*width px] (one gather per batch of frames)."""
         self._check(self._lib.rtamd_assemble_tile_batch_device(self._h, ctypes.c_void_p(gathered_ptr), width, height, tile_world,

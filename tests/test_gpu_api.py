@@ -381,6 +381,28 @@ def test_frames_in_flight_on_several_streams(tracer, atrium):
         tracer.set_stream(None)
 
 
+def test_display_pass_is_the_gl_unorm8_conversion(tracer):
+    """rtamd_display_rgba8_device against raytracer_amd.assets.frame_to_rgb8 (clamp, x255, round to nearest even):
+    random colours, exact halves, values outside [0,1], infinities and NaN; ragged pixel counts."""
+    import torch
+    from raytracer_amd import assets
+    rng = np.random.default_rng(4)
+    for n in (1, 63, 4097):
+        x = rng.uniform(-0.2, 1.2, (n, 4)).astype(np.float32)
+        k = min(n, 12)
+        x[:k, 0] = (np.arange(k, dtype=np.float32) + 0.5) / 255                     # exact ties after x255
+        x[:k, 1] = [np.inf, -np.inf, np.nan, 0.0, -0.0, 1.0, 0.5, 1e-30, 2.0, -1.0, 0.999999, 0.0019607844][:k]
+        d = torch.from_numpy(x).cuda()
+        out = torch.zeros((n,), dtype=torch.int32, device="cuda")
+        tracer.display_rgba8_device(d.data_ptr(), n, out.data_ptr())
+        tracer.synchronize()
+        got = out.cpu().numpy().view(np.uint8).reshape(n, 4)
+        a = np.nan_to_num(x, nan=0.0, posinf=1.0, neginf=0.0)
+        want = np.rint(np.clip(a, 0.0, 1.0) * np.float32(255.0)).astype(np.uint8)
+        assert np.array_equal(got, want)
+        assert np.array_equal(got[:, :3], assets.frame_to_rgb8(x, n, 1).reshape(n, 3))
+
+
 def test_two_contexts_render_concurrently(tracer, atrium):
     """Two contexts of one process on the same GPU (each with its own scene copy and launch scratch),
     frames issued alternately on streams of their own: every frame equals the one rendered alone."""
