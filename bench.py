@@ -8,8 +8,11 @@ uv interpolation, one sun shadow traversal, one bilinear texture fetch and the
 Phong/sky shading, RGBA32F out.  Rays (dir/org, 24 B per pixel), scene and
 textures are resident in HBM before the timed region.  With N > 1 ranks the
 frame is split into interleaved 32x32 tiles (scene replicated), every rank
-renders its tiles, one RCCL gather brings them to rank 0, which assembles the
-scan-line frame — all inside the timed step.
+renders its tiles (RGBA32F, as on one GPU) and converts them with the display pass
+(util/display.frag: float -> 8-bit back buffer), one RCCL gather per 4 frames brings
+the RGBA8 shares to rank 0, which assembles the scan-line frames — all inside the
+timed steps.  (--gather-format f32 moves the float shares instead: 33 MB per frame is
+138 GB/s at this frame rate, more than an xGMI link carries.)
 
 Frames in flight (default 4, 8 with N > 1): consecutive frames are issued round-robin on HIP
 streams (the library keeps per-stream launch scratch, include/rtamd.h), each into
@@ -103,9 +106,10 @@ def main():
                          "several GPUs, where a launch covers 1/N of the frame and is bounded by its slowest rays, not by throughput)")
     ap.add_argument("--gather-batch", type=int, default=0,
                     help="N > 1: frames per RCCL gather (0 = auto: 4 up to 1080p, 1 above)")
-    ap.add_argument("--gather-format", choices=("f32", "rgba8"), default="f32",
-                    help="N > 1: what crosses xGMI. f32 = the shader's RGBA32F target (default, like the reference's float "
-                         "framebuffers); rgba8 = the display pass's 8-bit back buffer (util/display.frag), a quarter of the bytes")
+    ap.add_argument("--gather-format", choices=("f32", "rgba8"), default="rgba8",
+                    help="N > 1: what crosses xGMI. rgba8 (default) = the display pass's 8-bit back buffer (util/display.frag) that "
+                         "every rank produces from its RGBA32F share; f32 = the RGBA32F shares themselves: 33 MB per 1080p frame, "
+                         "i.e. 138 GB/s at this frame rate — more than an xGMI link carries")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
