@@ -202,7 +202,7 @@ def main():
     frame = None
     as8 = world > 1 and args.gather_format == "rgba8"
     send = rgba
-    if as8:   # each rank converts its share with the display pass; the gather moves packed RGBA8
+    if as8:   # each rank also writes its share as the display pass would (8-bit back buffer); the gather moves that
         send = [torch.zeros((G * n_local_out,), dtype=torch.int32, device=dev) for _ in range(F)]
     if world > 1 and rank == 0:
         if as8:
@@ -250,13 +250,13 @@ def main():
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(rs)
+        # with the RGBA8 gather the kernel writes the display-format pixel beside the float one (rtamd_frame_out.rgba8)
         tracer.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=has_tc, has_normals=has_n,
-                             tile_rank=rank, tile_world=world, rgba_ptr=rgba[f].data_ptr() + g * n_local_out * 16)
+                             tile_rank=rank, tile_world=world, rgba_ptr=rgba[f].data_ptr() + g * n_local_out * 16,
+                             rgba8_ptr=(send[f].data_ptr() + g * n_local_out * 4) if as8 else 0)
         if timed:
             e1.record(rs)
             launch_events.append((e0, e1))
-        if as8:
-            tracer.display_rgba8_device(rgba[f].data_ptr() + g * n_local_out * 16, n_local_out, send[f].data_ptr() + g * n_local_out * 4)
         if world > 1:
             pending[0] = f
             if g == G - 1:

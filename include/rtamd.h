@@ -53,7 +53,7 @@ typedef struct rtamd_context rtamd_context;
  * ray_trace_and_shade.frag:201,232-234). */
 /* Bumped whenever a struct layout or the meaning of an argument changes; a binder compares its compile-time
  * value with rtamd_abi_version() of the library it loaded.  (No counterpart in the reference.) */
-#define RTAMD_ABI_VERSION 3
+#define RTAMD_ABI_VERSION 4
 uint32_t rtamd_abi_version(void);
 
 #define RTAMD_NO_HIT 0xFFFFFFFFu
@@ -187,6 +187,9 @@ typedef struct rtamd_frame_out {
     uint32_t *hit_id;  /* closest-hit triangle index (leaf order) or RTAMD_NO_HIT */
     float *hit_t;      /* primary t, or 1e6 (the shader's initial value, :199) on a miss */
     uint32_t *counts;  /* 2 per pixel: AABB tests, triangle tests (the shader's `intersections`, :115,123,138, split by kind; primary + shadow) */
+    uint32_t *rgba8;   /* the pixel as the display pass writes it to the 8-bit back buffer (util/display.frag:9; GL float -> unorm8:
+                        * clamp, x255, round to nearest), R in the low byte: rtamd_display_rgba8_device applied to rgba32f (which
+                        * must be given too) by the same call, behind the render kernel on the same stream */
 } rtamd_frame_out;
 
 /* Host buffers in, host buffers out; synchronous.  Replaces bind + set_uniform_* +

@@ -59,7 +59,7 @@ class FrameDesc(ctypes.Structure):
 class FrameOut(ctypes.Structure):
     _fields_ = [
         ("rgba32f", ctypes.c_void_p), ("hit_id", ctypes.c_void_p),
-        ("hit_t", ctypes.c_void_p), ("counts", ctypes.c_void_p),
+        ("hit_t", ctypes.c_void_p), ("counts", ctypes.c_void_p), ("rgba8", ctypes.c_void_p),
     ]
 
 
@@ -136,7 +136,7 @@ def host_lib():
     return _host
 
 
-ABI_VERSION = 3   # include/rtamd.h RTAMD_ABI_VERSION
+ABI_VERSION = 4   # include/rtamd.h RTAMD_ABI_VERSION
 
 
 def device_lib():

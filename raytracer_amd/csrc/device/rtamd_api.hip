@@ -730,9 +730,20 @@ int rtamd_render_device(rtamd_context *ctx, const rtamd_frame_desc *desc, const 
     int rc = check_frame(ctx, desc, out);
     if (rc) return rc;
     if ((rc = ensure_ctx_device(ctx))) return rc;
+    if (out->rgba8 && !out->rgba32f) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "rgba8 is made from rgba32f: pass both");
     JobParams p;
     fill_job(ctx, desc, out, p);
-    return launch_main(ctx, MODE_FUSED, out->counts != nullptr, p);
+    if ((rc = launch_main(ctx, MODE_FUSED, out->counts != nullptr, p))) return rc;
+    if (out->rgba8) {
+        // The display conversion runs as its own small launch behind the render kernel, on the same stream.  (Writing
+        // the 8-bit pixel from inside k_persistent was measured: the three extra conversions at each of the kernel's
+        // store sites cost the fused shader 18 % through register pressure; a separate instantiation was not worth it.)
+        const uint32_t n_tiles = n_tiles_of(desc->width, desc->height, nullptr);
+        const uint64_t n_out = desc->tile_world == 1 ? (uint64_t)desc->width * desc->height
+                                                     : (uint64_t)local_tiles(n_tiles, desc->tile_rank, desc->tile_world) * RTAMD_TILE_PIXELS;
+        return rtamd_display_rgba8_device(ctx, out->rgba32f, n_out, out->rgba8);
+    }
+    return RTAMD_OK;
 }
 
 int rtamd_render(rtamd_context *ctx, const rtamd_frame_desc *desc, const rtamd_frame_out *out) {
@@ -742,8 +753,8 @@ int rtamd_render(rtamd_context *ctx, const rtamd_frame_desc *desc, const rtamd_f
     const size_t n_px = (size_t)desc->width * desc->height;
     uint32_t n_tiles = n_tiles_of(desc->width, desc->height, nullptr);
     const size_t n_out = desc->tile_world == 1 ? n_px : (size_t)local_tiles(n_tiles, desc->tile_rank, desc->tile_world) * RTAMD_TILE_PIXELS;
-    DevBuf d_dir, d_org, d_rgba, d_id, d_t, d_cnt;
-    auto cleanup = [&]() { d_dir.release(); d_org.release(); d_rgba.release(); d_id.release(); d_t.release(); d_cnt.release(); };
+    DevBuf d_dir, d_org, d_rgba, d_id, d_t, d_cnt, d_rgba8;
+    auto cleanup = [&]() { d_dir.release(); d_org.release(); d_rgba.release(); d_id.release(); d_t.release(); d_cnt.release(); d_rgba8.release(); };
     rtamd_frame_desc dd = *desc;
     rtamd_frame_out od{};
     rc = RTAMD_OK;
@@ -757,6 +768,7 @@ int rtamd_render(rtamd_context *ctx, const rtamd_frame_desc *desc, const rtamd_f
         if (out->hit_id) { if ((rc = dev_alloc(ctx, d_id, n_out * 4))) break; od.hit_id = (uint32_t *)d_id.p; }
         if (out->hit_t) { if ((rc = dev_alloc(ctx, d_t, n_out * 4))) break; od.hit_t = (float *)d_t.p; }
         if (out->counts) { if ((rc = dev_alloc(ctx, d_cnt, n_out * 8))) break; od.counts = (uint32_t *)d_cnt.p; }
+        if (out->rgba8) { if ((rc = dev_alloc(ctx, d_rgba8, n_out * 4))) break; od.rgba8 = (uint32_t *)d_rgba8.p; }
         // pixels of partial edge tiles that fall outside the frame are never written: define them as 0
         if (desc->tile_world != 1) {
             hipError_t e = hipSuccess;
@@ -764,6 +776,7 @@ int rtamd_render(rtamd_context *ctx, const rtamd_frame_desc *desc, const rtamd_f
             if (e == hipSuccess && od.hit_id) e = hipMemsetAsync(od.hit_id, 0, n_out * 4, ctx->stream);
             if (e == hipSuccess && od.hit_t) e = hipMemsetAsync(od.hit_t, 0, n_out * 4, ctx->stream);
             if (e == hipSuccess && od.counts) e = hipMemsetAsync(od.counts, 0, n_out * 8, ctx->stream);
+            if (e == hipSuccess && od.rgba8) e = hipMemsetAsync(od.rgba8, 0, n_out * 4, ctx->stream);
             if (e != hipSuccess) { rc = fail(ctx, RTAMD_ERR_DEVICE, "hipMemsetAsync failed: %s", hipGetErrorString(e)); break; }
         }
         if ((rc = rtamd_render_device(ctx, &dd, &od))) break;
@@ -772,6 +785,7 @@ int rtamd_render(rtamd_context *ctx, const rtamd_frame_desc *desc, const rtamd_f
         if (out->rgba32f && (e = hipMemcpy(out->rgba32f, od.rgba32f, n_out * 16, hipMemcpyDeviceToHost)) != hipSuccess) { rc = fail(ctx, RTAMD_ERR_DEVICE, "copy-back failed: %s", hipGetErrorString(e)); break; }
         if (out->hit_id && (e = hipMemcpy(out->hit_id, od.hit_id, n_out * 4, hipMemcpyDeviceToHost)) != hipSuccess) { rc = fail(ctx, RTAMD_ERR_DEVICE, "copy-back failed: %s", hipGetErrorString(e)); break; }
         if (out->hit_t && (e = hipMemcpy(out->hit_t, od.hit_t, n_out * 4, hipMemcpyDeviceToHost)) != hipSuccess) { rc = fail(ctx, RTAMD_ERR_DEVICE, "copy-back failed: %s", hipGetErrorString(e)); break; }
+        if (out->rgba8 && (e = hipMemcpy(out->rgba8, od.rgba8, n_out * 4, hipMemcpyDeviceToHost)) != hipSuccess) { rc = fail(ctx, RTAMD_ERR_DEVICE, "copy-back failed: %s", hipGetErrorString(e)); break; }
         if (out->counts && (e = hipMemcpy(out->counts, od.counts, n_out * 8, hipMemcpyDeviceToHost)) != hipSuccess) { rc = fail(ctx, RTAMD_ERR_DEVICE, "copy-back failed: %s", hipGetErrorString(e)); break; }
     } while (0);
     cleanup();

@@ -166,20 +166,22 @@ class HipRayTracer:
             res["hit_id"] = np.zeros(n_out, np.uint32)
         if "hit_t" in want:
             res["hit_t"] = np.zeros(n_out, np.float32)
+        if "rgba8" in want:
+            res["rgba8"] = np.zeros((n_out,), np.uint32)
         if "counts" in want:
             res["counts"] = np.zeros((n_out, 2), np.uint32)
         d = self._frame_desc(width, height, _ptr(dir), _ptr(org), camera, has_tex_coords, has_normals, tile_rank, tile_world)
-        o = _ffi.FrameOut(_ptr(res.get("rgba")), _ptr(res.get("hit_id")), _ptr(res.get("hit_t")), _ptr(res.get("counts")))
+        o = _ffi.FrameOut(_ptr(res.get("rgba")), _ptr(res.get("hit_id")), _ptr(res.get("hit_t")), _ptr(res.get("counts")), _ptr(res.get("rgba8")))
         self._check(self._lib.rtamd_render(self._h, ctypes.byref(d), ctypes.byref(o)))
         return res
 
     def render_device(self, width, height, dir_ptr=0, org_ptr=0, camera=None, has_tex_coords=False, has_normals=False,
-                      tile_rank=0, tile_world=1, rgba_ptr=0, hit_id_ptr=0, hit_t_ptr=0, counts_ptr=0):
+                      tile_rank=0, tile_world=1, rgba_ptr=0, hit_id_ptr=0, hit_t_ptr=0, counts_ptr=0, rgba8_ptr=0):
         """Device-pointer render (rtamd_render_device): integers are raw device addresses
         (e.g. torch.Tensor.data_ptr()); asynchronous on the context's stream."""
         d = self._frame_desc(width, height, ctypes.c_void_p(dir_ptr or None) if dir_ptr else None,
                              ctypes.c_void_p(org_ptr) if org_ptr else None, camera, has_tex_coords, has_normals, tile_rank, tile_world)
-        o = _ffi.FrameOut(rgba_ptr or None, hit_id_ptr or None, hit_t_ptr or None, counts_ptr or None)
+        o = _ffi.FrameOut(rgba_ptr or None, hit_id_ptr or None, hit_t_ptr or None, counts_ptr or None, rgba8_ptr or None)
         self._check(self._lib.rtamd_render_device(self._h, ctypes.byref(d), ctypes.byref(o)))
 
     # ---- split-pipeline trace --------------------------------------------

@@ -403,6 +403,36 @@ def test_display_pass_is_the_gl_unorm8_conversion(tracer):
         assert np.array_equal(got[:, :3], assets.frame_to_rgb8(x, n, 1).reshape(n, 3))
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+def test_fused_rgba8_output_equals_the_display_pass(tracer, atrium, variant):
+    """rtamd_frame_out.rgba8: the kernel's own 8-bit pixel equals rtamd_display_rgba8_device applied to its float
+    pixel and the host writer's conversion; whole frame and a tile shard."""
+    import torch
+    from raytracer_amd import assets
+    sc, camera, tex = atrium
+    W, H = 333, 187
+    tracer.upload_scene(sc)
+    tracer.upload_texture(0, tex[0]); tracer.upload_texture(1, tex[1])
+    inv = camera.inv_proj_view()
+    try:
+        tracer.set_kernel_variant(variant)
+        r = tracer.render(W, H, camera=(inv, camera.position), has_tex_coords=1, has_normals=1, want=("rgba", "rgba8"))
+        part = tracer.render(W, H, camera=(inv, camera.position), has_tex_coords=1, has_normals=1, tile_rank=1, tile_world=3, want=("rgba", "rgba8"))
+    finally:
+        tracer.set_kernel_variant(0)
+    for res in (r, part):
+        n = len(res["rgba"])
+        d = torch.from_numpy(res["rgba"]).cuda()
+        out = torch.zeros((n,), dtype=torch.int32, device="cuda")
+        tracer.display_rgba8_device(d.data_ptr(), n, out.data_ptr())
+        tracer.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), res["rgba8"])
+    assert np.array_equal(r["rgba8"].view(np.uint8).reshape(H, W, 4)[::-1, :, :3], assets.frame_to_rgb8(r["rgba"], W, H))
+    assert np.all(r["rgba8"] >> 24 == 255)
+    with pytest.raises(RtamdError):
+        tracer.render(W, H, camera=(inv, camera.position), has_tex_coords=1, has_normals=1, want=("rgba8",))
+
+
 def test_two_contexts_render_concurrently(tracer, atrium):
     """Two contexts of one process on the same GPU (each with its own scene copy and launch scratch),
     frames issued alternately on streams of their own: every frame equals the one rendered alone."""
