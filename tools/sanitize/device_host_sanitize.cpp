@@ -67,7 +67,8 @@ int main() {
         for (size_t i = 0; i < n; i++) { org[3 * i] = -3.f + 6.f * (i % w) / w; org[3 * i + 1] = -3.f + 6.f * (i / w) / h; org[3 * i + 2] = 45.f; dir[3 * i + 2] = -1.f; }
         rtamd_frame_desc d{}; d.width = w; d.height = h; d.dir = dir.data(); d.org = org.data(); d.has_tex_coords = 1; d.has_normals = 1; d.tile_rank = 0; d.tile_world = 1;
         d.near_plane = 0.01f; d.far_plane = 1000.f;
-        rtamd_frame_out o{rgba.data(), id.data(), t.data(), cnt.data()};
+        std::vector<uint32_t> px8(n);
+        rtamd_frame_out o{rgba.data(), id.data(), t.data(), cnt.data(), px8.data()};
         CHECK(rtamd_render(ctx, &d, &o) == RTAMD_OK);
         CHECK(rtamd_trace(ctx, n, org.data(), dir.data(), hits.data()) == RTAMD_OK);
         size_t nh = 0; for (size_t i = 0; i < n; i++) nh += id[i] != RTAMD_NO_HIT;
@@ -94,6 +95,7 @@ int main() {
             CHECK(rtamd_set_option(ctx, opt, v) == RTAMD_OK);
             for (int k = 0; k < 12; k++) { CHECK(rtamd_context_set_stream(ctx, st[k % 10]) == RTAMD_OK); rtamd_frame_out o{d_rgba + (k % 10) * n * 4, nullptr, nullptr, nullptr}; CHECK(rtamd_render_device(ctx, &d, &o) == RTAMD_OK); }
         }
+    CHECK(rtamd_abi_version() == RTAMD_ABI_VERSION);
     CHECK(rtamd_set_option(ctx, "no_such", 1) != RTAMD_OK);
     CHECK(hipDeviceSynchronize() == hipSuccess);
     float u, l; uint32_t th; (void)rtamd_last_launch_coherence(ctx, &u, &l, &th);
