@@ -326,6 +326,20 @@ def main():
     kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in launch_events]))
     tracer.set_stream(stream.cuda_stream)
 
+    # ---- untimed extra for the record: the same frame one at a time (what a caller that waits for every frame
+    # sees); `value` and `ms_per_step` above are the pipelined figures
+    serial_ms = None
+    if world == 1 and F > 1:
+        n_serial = max(10, min(200, args.steps))
+        torch.cuda.synchronize()
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record(stream)
+        for _ in range(n_serial):
+            tracer.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=has_tc, has_normals=has_n, rgba_ptr=rgba[0].data_ptr())
+        s1.record(stream)
+        torch.cuda.synchronize()
+        serial_ms = s0.elapsed_time(s1) / n_serial
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -366,7 +380,8 @@ def main():
                                f"{W}x{H}, 1 spp, primary + sun shadow ray + shading (fused ray_trace_and_shade semantics)",
                    "rays_per_frame": rays_per_frame, "primary_rays": n_primary_all, "shadow_rays": n_shadow_all,
                    "parallelism": f"tiles{world}" if world > 1 else "single", "kernel_variant": args.variant,
-                   "frames_in_flight": F, **({"frames_per_gather": G, "gather_format": args.gather_format} if world > 1 else {}), "shadow_rays_stop_at_first_occluder": True,
+                   "frames_in_flight": F, **({"frames_per_gather": G, "gather_format": args.gather_format} if world > 1 else {}),
+                   **({"ms_per_frame_one_at_a_time": round(serial_ms, 5)} if serial_ms is not None else {}), "shadow_rays_stop_at_first_occluder": True,
                    **({"assembled_frame_equals_single_gpu_frame": frame_check} if frame_check is not None else {}),
                    **({"REHEARSAL_not_a_measurement": "all ranks on cuda:0, gloo gather through host memory"} if rehearse else {}),
                    "bvh_build_s": round(build_s, 2)},
