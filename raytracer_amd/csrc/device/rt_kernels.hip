@@ -22,9 +22,10 @@
 // queues (one queue per XCD-sized slice of the item list, with stealing) and
 // re-fill idle lanes (ballot + mbcnt compaction of the pending-pixel pool) when
 // fewer than `dyn_thresh` lanes are still traversing.  k_static (one lane per
-// pixel, no re-fill) is kept as the A/B baseline.  Per-lane traversal stacks live
-// in LDS ([entry][thread], conflict-free for ds_read/write_b32) and spill to
-// scratch beyond LDS_STACK_ENTRIES.
+// pixel, no re-fill) is kept as the A/B baseline.  Per-lane traversal stacks keep
+// their top LDS_STACK_ENTRIES entries in an LDS ring ([entry][thread], conflict-free
+// for ds_read/write_b32); older entries move to per-lane HBM columns (k_static:
+// LDS + private scratch).
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <stdint.h>
@@ -43,8 +44,9 @@ constexpr float T_HIT_LIMIT = 1000.0f;    // :206,219
 constexpr int BLOCK = RTAMD_BLOCK;   // threads per workgroup of the traversal kernels (multiple of 64)
 // k_persistent is latency-bound: occupancy matters.  8 waves per SIMD (<= 64 VGPRs; the
 // register spills this forces sit in the shading code and in the rare stack-overflow
-// branches, not in the visit loop) measured 4 % faster than 6 (<= 80 VGPRs) with frames
-// in flight on coherent rays, 4 % slower on shuffled (incoherent) rays; 5 is 4 % slower.
+// branches, not in the visit loop) measured, with four frames in flight, 3 % faster than 7
+// (<= 72 VGPRs) and 10 % faster than 6 (<= 80 VGPRs) on coherent rays, 15 % faster on shuffled
+// soup rays.
 #ifndef RTAMD_WAVES_PER_EU
 #define RTAMD_WAVES_PER_EU 8
 #endif
