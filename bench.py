@@ -44,7 +44,9 @@ if _hwq != "0":
     os.environ["GPU_MAX_HW_QUEUES"] = str(max(1, min(32, int(_hwq))))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-VALU_PEAK_TOPS = 78.6        # 157.3 TFLOP/s FMA-counted fp32 vector = 78.6 T un-fused op/s
+VALU_PEAK_TOPS = 78.6        # 157.3 TFLOP/s FMA-count
+VALU_NS_PER_WAVE_INSTR = 1.0  # tools/micro/valu_ops.hip on MI355X: v_mul/v_sub/v_mov, and the visit's mix of classes
+N_SIMDS = 1024               # 256 CUs x 4ed fp32 vector = 78.6 T un-fused op/s
 
 
 WORKLOAD_NOTE = {"atrium_1080p": "procedural Sponza-class atrium", "atrium_small": "procedural Sponza-class atrium",
@@ -402,7 +404,15 @@ def main():
     # (cannot be collected live: PMC runs serialise kernels); see profiles/.
     tpath = os.path.join(REPO, "profiles", f"traffic_{args.workload}.json")
     if world == 1 and args.variant == 0 and os.path.exists(tpath):
-        out["roofline"]["traffic"] = json.load(open(tpath))["traffic_bytes_per_launch"]
+        prof = json.load(open(tpath))
+        out["roofline"]["traffic"] = prof["traffic_bytes_per_launch"]
+        if "valu_wave_instructions_per_launch" in prof:
+            # what actually bounds the kernel: VALU issue.  Instructions per launch from the committed PMC pass,
+            # issue rate from the micro-benchmark (1.0 ns per wave64 instruction per SIMD, 1024 SIMDs), over the
+            # time one frame takes in the pipeline
+            busy_ms = prof["valu_wave_instructions_per_launch"] * VALU_NS_PER_WAVE_INSTR * 1e-6 / N_SIMDS
+            out["roofline"]["valu"]["issue_frac"] = round(busy_ms / job_ms, 4)
+            out["roofline"]["valu"]["wave_instructions_per_launch"] = prof["valu_wave_instructions_per_launch"]
 
     if world == 1 and not args.no_cpu_baseline:
         # oracle A (the CPU restatement) on the same frame, bounded: every 2nd pixel row
