@@ -238,7 +238,7 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
             for (const auto &o : ctx->slots)
                 if (&o != sl && o.bound && o.ev_valid && hipEventQuery(o.ev_stop) == hipErrorNotReady) inflight++;
             (void)hipGetLastError();   // hipErrorNotReady is an answer, not a failure
-            const int share = 16 / inflight;
+            const int share = (16 * 256 / BLOCK) / inflight;   // 16 workgroups of 256 threads per CU, in units of this build's workgroup
             if (share < per_cu) per_cu = share < 1 ? 1 : share;
         }
         uint32_t grid = (uint32_t)(ctx->num_cu * per_cu);
