@@ -149,10 +149,22 @@ int query_blocks(rtamd_context *ctx, K kernel, int *out) {
     return RTAMD_OK;
 }
 
-int ensure_ctx_device(rtamd_context *ctx) {
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return RTAMD_OK;
-}
+// Every entry point that touches the GPU makes the context's device current for the duration of the
+// call and puts the caller's device back on return: a process that drives several GPUs (one context each)
+// keeps its own current device across calls into the library.
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    int enter(rtamd_context *ctx) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != ctx->device) {
+            HIP_TRY(ctx, hipSetDevice(ctx->device));
+            switched = true;
+        }
+        return RTAMD_OK;
+    }
+    ~DeviceScope() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+};
 
 constexpr size_t QUEUE_HEADROOM_WORDS = 64;   // room for the odd launches' statistics pair in front of the counters
 constexpr size_t QUEUE_BYTES = 256 + 32 * 16384 + 256;   // headroom + (num_queues <= 32) * (queue_stride <= 4096 words) + the even pair
@@ -324,7 +336,8 @@ int rtamd_context_create(int device_ordinal, rtamd_context **out_ctx) {
     ctx->device = device_ordinal;
     auto bail = [&](int code) { g_create_error = ctx->err; rtamd_context_destroy(ctx); return code; };
     int rc;
-    if ((rc = ensure_ctx_device(ctx))) return bail(rc);
+    DeviceScope dev_scope;
+    if ((rc = dev_scope.enter(ctx))) return bail(rc);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) { ctx->err = "hipGetDeviceProperties failed"; return bail(RTAMD_ERR_DEVICE); }
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -363,7 +376,8 @@ int rtamd_context_create(int device_ordinal, rtamd_context **out_ctx) {
 
 void rtamd_context_destroy(rtamd_context *ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    DeviceScope dev_scope;
+    (void)dev_scope.enter(ctx);
     (void)hipDeviceSynchronize();   // launches may be in flight on several (caller-owned) streams
     ctx->nodes.release(); ctx->tris.release(); ctx->big.release(); ctx->tri_idx.release();
     ctx->normals.release(); ctx->texcoords.release(); for (auto &t : ctx->tex) t.release(); ctx->materials.release(); ctx->tex_slots.release(); ctx->noise.release();
@@ -387,7 +401,8 @@ int rtamd_context_set_stream(rtamd_context *ctx, void *hip_stream) {
 
 int rtamd_synchronize(rtamd_context *ctx) {
     if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
-    int rc = ensure_ctx_device(ctx);
+    DeviceScope dev_scope;
+    int rc = dev_scope.enter(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RTAMD_OK;
@@ -443,7 +458,8 @@ int rtamd_upload_scene(rtamd_context *ctx, const rtamd_scene_desc *sc) {
     if (!sc->nodes || !sc->triangles || !sc->positions || sc->node_count == 0 || sc->triangle_count == 0 || sc->vertex_count == 0)
         return fail(ctx, RTAMD_ERR_EMPTY_SCENE, "empty scene (nodes %u, triangles %u, vertices %u)", sc->node_count, sc->triangle_count, sc->vertex_count);
     if (sc->triangle_count > MAX_TRIANGLES) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "more than %u triangles are not supported", MAX_TRIANGLES);
-    int rc = ensure_ctx_device(ctx);
+    DeviceScope dev_scope;
+    int rc = dev_scope.enter(ctx);
     if (rc) return rc;
     const RefNode *nodes = (const RefNode *)sc->nodes;
     const RefTriangle *tris = (const RefTriangle *)sc->triangles;
@@ -575,7 +591,8 @@ namespace {
 // GL_RGB / UNSIGNED_BYTE rows (taken as tightly packed, first row first) -> RGBA8 texels in HBM.
 int upload_rgb8(rtamd_context *ctx, DevBuf &dst, const uint8_t *rgb8, uint32_t width, uint32_t height) {
     if (!rgb8 || width == 0 || height == 0 || width > 32768 || height > 32768) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "bad texture %ux%u", width, height);
-    int rc = ensure_ctx_device(ctx);
+    DeviceScope dev_scope;
+    int rc = dev_scope.enter(ctx);
     if (rc) return rc;
     try {
         // The reference uploads with the default GL_UNPACK_ALIGNMENT of 4 (texture.rs:14-24 never
@@ -587,9 +604,15 @@ int upload_rgb8(rtamd_context *ctx, DevBuf &dst, const uint8_t *rgb8, uint32_t w
             for (uint32_t x = 0; x < width; x++)
                 rgba[(size_t)y * width + x] = (uint32_t)row[3 * x] | ((uint32_t)row[3 * x + 1] << 8) | ((uint32_t)row[3 * x + 2] << 16) | 0xFF000000u;
         }
+        // The new texels go into a buffer of their own first: if the allocation or the copy fails, the slot
+        // (and every pointer the kernels hold to it: sdev.tex[], the tex_slots table) keeps the old, live texels.
+        DevBuf fresh;
+        if ((rc = dev_upload(ctx, fresh, rgba.data(), rgba.size() * 4))) { fresh.release(); return rc; }
         // a frame in flight may still sample the old texels
-        HIP_TRY(ctx, hipDeviceSynchronize());
-        if ((rc = dev_upload(ctx, dst, rgba.data(), rgba.size() * 4))) return rc;
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) { fresh.release(); return fail(ctx, RTAMD_ERR_DEVICE, "hipDeviceSynchronize failed: %s", hipGetErrorString(e)); }
+        dst.release();
+        dst = fresh;
     } catch (const std::bad_alloc &) {
         return fail(ctx, RTAMD_ERR_OUT_OF_MEMORY, "out of host memory");
     }
@@ -625,14 +648,19 @@ int rtamd_upload_texture(rtamd_context *ctx, uint32_t slot, const uint8_t *rgb8,
         ctx->sdev.tex[slot] = (const uint32_t *)ctx->tex[slot].p;
         ctx->sdev.tex_w[slot] = (int32_t)width; ctx->sdev.tex_h[slot] = (int32_t)height;
     }
-    if (ctx->sdev.materials) return refresh_tex_slots(ctx);
+    if (ctx->sdev.materials && (rc = refresh_tex_slots(ctx))) {
+        // the slot table could not be rewritten and may still name the texels just freed: no launch may read it
+        ctx->sdev.materials = nullptr; ctx->n_materials = 0;
+        return rc;
+    }
     return RTAMD_OK;
 }
 
 int rtamd_upload_materials(rtamd_context *ctx, const rtamd_shading_material *materials, uint32_t count) {
     if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
     if (!ctx->has_scene) return fail(ctx, RTAMD_ERR_NO_SCENE, "no scene uploaded (the table is checked against the scene's material indices)");
-    int rc = ensure_ctx_device(ctx);
+    DeviceScope dev_scope;
+    int rc = dev_scope.enter(ctx);
     if (rc) return rc;
     if (count == 0) {   // back to the shader's constants
         HIP_TRY(ctx, hipDeviceSynchronize());
@@ -680,7 +708,8 @@ int rtamd_dispatch_rays_device(rtamd_context *ctx, const rtamd_dispatch_desc *d,
     if (!d->position || !d->normal_mat) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "position / normal_mat is NULL");
     if (((uintptr_t)d->position | (uintptr_t)d->normal_mat | (uintptr_t)o->org | (uintptr_t)o->shadow_dir | (uintptr_t)o->reflect_dir | (uintptr_t)o->ambient_dir) & 15u)
         return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "device buffers must be 16-byte aligned");
-    int rc = ensure_ctx_device(ctx);
+    DeviceScope dev_scope;
+    int rc = dev_scope.enter(ctx);
     if (rc) return rc;
     DispatchParams p{};
     p.position = d->position; p.normal_mat = d->normal_mat;
@@ -699,7 +728,8 @@ int rtamd_dispatch_rays(rtamd_context *ctx, const rtamd_dispatch_desc *d, const 
     if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
     if (!d || !o) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "dispatch descriptor / output is NULL");
     if (d->width == 0 || d->height == 0 || !d->position || !d->normal_mat) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "bad dispatch arguments");
-    int rc = ensure_ctx_device(ctx);
+    DeviceScope dev_scope;
+    int rc = dev_scope.enter(ctx);
     if (rc) return rc;
     const size_t n = (size_t)d->width * d->height;
     DevBuf d_pos, d_nm, d_out[4];
@@ -729,7 +759,8 @@ int rtamd_dispatch_rays(rtamd_context *ctx, const rtamd_dispatch_desc *d, const 
 int rtamd_render_device(rtamd_context *ctx, const rtamd_frame_desc *desc, const rtamd_frame_out *out) {
     int rc = check_frame(ctx, desc, out);
     if (rc) return rc;
-    if ((rc = ensure_ctx_device(ctx))) return rc;
+    DeviceScope dev_scope;
+    if ((rc = dev_scope.enter(ctx))) return rc;
     if (out->rgba8 && !out->rgba32f) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "rgba8 is made from rgba32f: pass both");
     JobParams p;
     fill_job(ctx, desc, out, p);
@@ -798,7 +829,8 @@ int rtamd_trace_device(rtamd_context *ctx, uint64_t n, const float *org, const f
     if (n == 0) return RTAMD_OK;
     if (!org || !dir || !hits) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "org / dir / hits is NULL");
     if (n > 0xFFFFFFFFull) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "at most 2^32-1 rays per call");
-    int rc = ensure_ctx_device(ctx);
+    DeviceScope dev_scope;
+    int rc = dev_scope.enter(ctx);
     if (rc) return rc;
     JobParams p;
     std::memset(&p, 0, sizeof p);
@@ -813,7 +845,8 @@ int rtamd_trace(rtamd_context *ctx, uint64_t n, const float *org, const float *d
     if (!ctx->has_scene) return fail(ctx, RTAMD_ERR_NO_SCENE, "no scene uploaded");
     if (n == 0) return RTAMD_OK;
     if (!org || !dir || !hits) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "org / dir / hits is NULL");
-    int rc = ensure_ctx_device(ctx);
+    DeviceScope dev_scope;
+    int rc = dev_scope.enter(ctx);
     if (rc) return rc;
     DevBuf d_org, d_dir, d_hits;
     do {
@@ -835,7 +868,8 @@ int rtamd_generate_rays_offset_device(rtamd_context *ctx, uint32_t width, uint32
     if (!inv_proj_view || !dir_out || width == 0 || height == 0) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "bad generate_rays arguments");
     if ((uint64_t)width * height > 0x7FFFFFFFull) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "frame too large");
     if (!(offset_x >= 0.0f && offset_x <= 1.0f && offset_y >= 0.0f && offset_y <= 1.0f)) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "sample offset must lie in [0,1]^2");
-    int rc = ensure_ctx_device(ctx);
+    DeviceScope dev_scope;
+    int rc = dev_scope.enter(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->ipv.p, inv_proj_view, 64, hipMemcpyHostToDevice, ctx->stream));
     uint32_t n = width * height;
@@ -861,7 +895,8 @@ int rtamd_surface_from_hits_device(rtamd_context *ctx, uint64_t n, const float *
     if (n > 0xFFFFFFFFull) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "at most 2^32-1 rays per call");
     if (has_normals && !ctx->normals.p) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "has_normals set but the scene has no normals");
     if (((uintptr_t)hits | (uintptr_t)normal_mat) & 15u) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "hits / normal_mat must be 16-byte aligned");
-    int rc = ensure_ctx_device(ctx);
+    DeviceScope dev_scope;
+    int rc = dev_scope.enter(ctx);
     if (rc) return rc;
     hipLaunchKernelGGL(k_surface_from_hits, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sdev, n, org, dir, hits,
                        has_normals ? 1u : 0u, position, normal_mat);
@@ -874,7 +909,8 @@ int rtamd_surface_from_hits(rtamd_context *ctx, uint64_t n, const float *org, co
     if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
     if (n == 0) return RTAMD_OK;
     if (!org || !dir || !hits || !position || !normal_mat) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "surface_from_hits: NULL buffer");
-    int rc = ensure_ctx_device(ctx);
+    DeviceScope dev_scope;
+    int rc = dev_scope.enter(ctx);
     if (rc) return rc;
     DevBuf d_org, d_dir, d_hits, d_pos, d_nm;
     do {
@@ -895,7 +931,8 @@ int rtamd_generate_rays(rtamd_context *ctx, uint32_t width, uint32_t height, con
                         float near_plane, float far_plane, float *dir_out) {
     if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
     if (!inv_proj_view || !dir_out || width == 0 || height == 0) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "bad generate_rays arguments");
-    int rc = ensure_ctx_device(ctx);
+    DeviceScope dev_scope;
+    int rc = dev_scope.enter(ctx);
     if (rc) return rc;
     DevBuf d;
     size_t bytes = (size_t)width * height * 12;
@@ -920,7 +957,8 @@ int rtamd_assemble_tile_batch_device(rtamd_context *ctx, const void *gathered, u
     if (!gathered || !frames_out || width == 0 || height == 0 || tile_world == 0 || elems_per_pixel == 0 || elems_per_pixel > 4 ||
         n_frames == 0 || n_frames > 65535u || (uint64_t)width * height > 0x7FFFFFFFull)
         return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "bad assemble_tiles arguments");
-    int rc = ensure_ctx_device(ctx);
+    DeviceScope dev_scope;
+    int rc = dev_scope.enter(ctx);
     if (rc) return rc;
     uint32_t tiles_x = 0;
     uint32_t n_tiles = n_tiles_of(width, height, &tiles_x);
@@ -942,7 +980,8 @@ int rtamd_display_rgba8_device(rtamd_context *ctx, const float *rgba32f, uint64_
     if (n_pixels == 0) return RTAMD_OK;
     if (!rgba32f || !rgba8_out || n_pixels > 0x7FFFFFFFull * 256ull) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "bad display arguments");
     if ((uintptr_t)rgba32f & 15u) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "rgba32f must be 16-byte aligned");
-    int rc = ensure_ctx_device(ctx);
+    DeviceScope dev_scope;
+    int rc = dev_scope.enter(ctx);
     if (rc) return rc;
     hipLaunchKernelGGL(k_display_rgba8, dim3((uint32_t)((n_pixels + 255) / 256)), dim3(256), 0, ctx->stream, (const float4 *)rgba32f, n_pixels, rgba8_out);
     HIP_TRY(ctx, hipGetLastError());
