@@ -53,7 +53,7 @@ typedef struct rtamd_context rtamd_context;
  * ray_trace_and_shade.frag:201,232-234). */
 /* Bumped whenever a struct layout or the meaning of an argument changes; a binder compares its compile-time
  * value with rtamd_abi_version() of the library it loaded.  (No counterpart in the reference.) */
-#define RTAMD_ABI_VERSION 4
+#define RTAMD_ABI_VERSION 5
 uint32_t rtamd_abi_version(void);
 
 #define RTAMD_NO_HIT 0xFFFFFFFFu
@@ -200,6 +200,20 @@ int rtamd_render(rtamd_context *ctx, const rtamd_frame_desc *desc, const rtamd_f
 /* Same, with desc->dir / desc->org and every pointer in `out` being DEVICE
  * pointers; enqueues on the context's stream and returns. */
 int rtamd_render_device(rtamd_context *ctx, const rtamd_frame_desc *desc, const rtamd_frame_out *out);
+
+/* rtamd_render_device for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same outputs bit for bit, but the call
+ * allocates nothing (no hipMalloc / hipFree, no event or stream creation): the launch scratch the persistent kernel
+ * needs — 8 work-queue counters and the HBM columns that take the bottom of deep traversal stacks — lives in a static
+ * device array of the library's code object, 64 MiB + 22 KiB, which every GPU the library runs on holds until the
+ * process ends.  Limits: the uploaded scene's tree may be at most 48 levels deep (rtamd_scene_info.max_depth; 16
+ * stack entries per lane in LDS + 32 in the static array), else RTAMD_ERR_INVALID_ARGUMENT; frame size as for
+ * rtamd_render_device.  It always runs the persistent kernel with the context's fixed lane re-fill threshold (no
+ * coherence feedback, no per-launch timing events: rtamd_last_kernel_ms / rtamd_last_launch_coherence do not see it).
+ * All calls on one GPU share that GPU's array — across streams and across contexts: calls that overlap on one GPU
+ * race (wrong pixels, never a fault); order them on one stream or with events.  The array keeps the last call's
+ * contents; the call clears the counters itself (one 2 KB hipMemsetAsync on the context's stream). */
+int rtamd_render_device_static(rtamd_context *ctx, const rtamd_frame_desc *desc, const rtamd_frame_out *out);
 
 /* ---- split-pipeline trace: ray_trace/ray_trace.frag:main (:131-143) -------- */
 

@@ -136,7 +136,7 @@ def host_lib():
     return _host
 
 
-ABI_VERSION = 4   # include/rtamd.h RTAMD_ABI_VERSION
+ABI_VERSION = 5   # include/rtamd.h RTAMD_ABI_VERSION
 
 
 def device_lib():
@@ -175,7 +175,7 @@ def device_lib():
         L.rtamd_upload_texture.restype = ctypes.c_int
         L.rtamd_upload_materials.argtypes = [vp, vp, ctypes.c_uint32]
         L.rtamd_upload_materials.restype = ctypes.c_int
-        for name in ("rtamd_render", "rtamd_render_device"):
+        for name in ("rtamd_render", "rtamd_render_device", "rtamd_render_device_static"):
             getattr(L, name).argtypes = [vp, ctypes.POINTER(FrameDesc), ctypes.POINTER(FrameOut)]
             getattr(L, name).restype = ctypes.c_int
         for name in ("rtamd_trace", "rtamd_trace_device"):

@@ -113,7 +113,8 @@ struct JobParams {
     uint32_t dyn_auto;            // 1: pick the lane re-fill threshold from stats_prev (coherent: 1, incoherent: dyn_incoherent)
     uint32_t dyn_incoherent;
     uint32_t queue_block;         // consecutive schedule positions a queue owns per turn
-    uint32_t *spill;              // k_persistent: [wave slot][SPILL_STACK_ENTRIES][64] stack overflow area
+    uint32_t *spill;              // k_persistent: [wave slot][spill_wave_words / 64 entries][64] stack overflow area
+    uint32_t spill_wave_words;    // u32 words per wave slot of `spill` (SPILL_STACK_ENTRIES * 64 for the context's own areas)
 #ifdef RTAMD_EXP_STAMPS
     unsigned long long *stamps;   // diagnostic build only: per wave {start, end, items, xcc} in 100 MHz ticks
 #endif
@@ -611,7 +612,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     StackGlobal st;
     st.lds = lds_stack;
-    st.spill = p.spill + ((size_t)(blockIdx.x * (BLOCK / 64) + (tid >> 6)) * SPILL_STACK_ENTRIES) * 64u + lane;
+    st.spill = p.spill + (size_t)(blockIdx.x * (BLOCK / 64) + (tid >> 6)) * p.spill_wave_words + lane;
 
     // wave-uniform pool of pending pixels / rays: item `pool_item`, lanes [pool_next, 64)
     uint32_t pool_item = 0, pool_next = 64;

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -56,6 +57,7 @@ struct rtamd_context {
     std::string err;
     int variant = 0;
     int num_cu = 0;
+    uint32_t *static_scratch = nullptr;   // device address of the code object's static launch scratch on this GPU (rtamd_render_device_static)
     int persistent_blocks_per_cu[6] = {0, 0, 0, 0, 0, 0};  // [mode*2 + count]; [4 + count]: fused with a material table
     // scene
     bool has_scene = false;
@@ -211,6 +213,7 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     p.shadow_anyhit = ctx->shadow_anyhit ? 1u : 0u;
     p.queue_stride = ctx->queue_stride; p.queue_block = mode == MODE_FUSED ? ctx->queue_block_fused : ctx->queue_block_trace;
     p.spill = (uint32_t *)sl->spill.p;
+    p.spill_wave_words = (uint32_t)SPILL_STACK_ENTRIES * 64u;
 #ifdef RTAMD_EXP_STAMPS
     p.stamps = (unsigned long long *)ctx->stamps.p;
 #endif
@@ -283,6 +286,44 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(sl->ev_stop, st));
     sl->ev_valid = true;
+    return RTAMD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Launch scratch of rtamd_render_device_static, the entry point that allocates nothing (include/rtamd.h).
+// The persistent kernel needs two pieces of device memory beyond inputs and outputs: the work-queue
+// counters and the per-wave HBM columns that take the bottom of deep traversal stacks.  Every other entry
+// point gets them from hipMalloc (one set per stream, acquire_slot); this one keeps them in ONE array that
+// is part of the code object, so every GPU the library runs on holds its own copy until the process ends:
+//   [ 8 queue counters, 256 B apart (2 KB) | stack columns [8192 waves][32 entries][64 lanes] u32 (64 MiB) | guard ]
+// 8192 waves = the full persistent grid (256 CUs x 8 workgroups x 4 waves); 32 entries beyond the 16 of the
+// LDS ring = trees up to depth 48 (deeper scenes are refused by the entry point; the guard keeps even the
+// kernel's own compile-time entry bound, SPILL_STACK_ENTRIES, inside the array for the last wave).
+// `scratch` is a host-side stand-in here, not a device address: host code uses static_scratch_ptr().
+constexpr uint32_t STATIC_WAVES = 8192;
+constexpr uint32_t STATIC_SPILL_ENTRIES = 32;
+constexpr uint32_t STATIC_MAX_DEPTH = (uint32_t)LDS_STACK_ENTRIES + STATIC_SPILL_ENTRIES;
+constexpr uint32_t STATIC_QUEUES = 8, STATIC_QUEUE_STRIDE = 64;
+constexpr size_t STATIC_QUEUE_WORDS = (size_t)STATIC_QUEUES * STATIC_QUEUE_STRIDE;
+constexpr size_t STATIC_SPILL_WORDS = (size_t)STATIC_WAVES * STATIC_SPILL_ENTRIES * 64;
+constexpr size_t STATIC_GUARD_WORDS = (size_t)(SPILL_STACK_ENTRIES > (int)STATIC_SPILL_ENTRIES ? SPILL_STACK_ENTRIES - (int)STATIC_SPILL_ENTRIES : 0) * 64;
+static __device__ __align__(256) uint32_t scratch[STATIC_QUEUE_WORDS + STATIC_SPILL_WORDS + STATIC_GUARD_WORDS];
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+uint32_t *g_scratch_ptr[MAX_DEVICES] = {};
+
+// The device address of `scratch` on the context's GPU (which must be current): looked up once per device.
+int static_scratch_ptr(rtamd_context *ctx, uint32_t **out) {
+    if (ctx->device < 0 || ctx->device >= MAX_DEVICES) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "device ordinal %d beyond %d", ctx->device, MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[ctx->device]) {
+        uint32_t *ptr = nullptr;
+        HIP_TRY(ctx, hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(ctx, RTAMD_ERR_DEVICE, "hipGetSymbolAddress returned NULL for the static launch scratch");
+        g_scratch_ptr[ctx->device] = ptr;
+    }
+    *out = g_scratch_ptr[ctx->device];
     return RTAMD_OK;
 }
 
@@ -363,6 +404,7 @@ int rtamd_context_create(int device_ordinal, rtamd_context **out_ctx) {
     if ((rc = dev_alloc(ctx, ctx->stamps, 65536 * 128 + 65536 * 32))) return bail(rc);
     (void)hipMemset(ctx->stamps.p, 0, ctx->stamps.bytes);
 #endif
+    if ((rc = static_scratch_ptr(ctx, &ctx->static_scratch))) return bail(rc);
     const uint32_t white = 0xFFFFFFFFu;
     if ((rc = dev_upload(ctx, ctx->white, &white, 4))) return bail(rc);
     {   // the slot of the context's own stream exists from the start: allocation failures surface here
@@ -777,10 +819,67 @@ int rtamd_render_device(rtamd_context *ctx, const rtamd_frame_desc *desc, const 
     return RTAMD_OK;
 }
 
+int rtamd_render_device_static(rtamd_context *ctx, const rtamd_frame_desc *desc, const rtamd_frame_out *out) {
+    int rc = check_frame(ctx, desc, out);
+    if (rc) return rc;
+    if (out->rgba8 && !out->rgba32f) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "rgba8 is made from rgba32f: pass both");
+    if (ctx->info.max_depth > STATIC_MAX_DEPTH)
+        return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "the scene's tree is %u levels deep; the static launch scratch holds traversal stacks for at most %u "
+                    "(use rtamd_render_device, which allocates its stack columns)", ctx->info.max_depth, STATIC_MAX_DEPTH);
+    DeviceScope dev_scope;
+    if ((rc = dev_scope.enter(ctx))) return rc;
+    uint32_t *const ptr = ctx->static_scratch;   // this GPU's copy of `scratch` (hipGetSymbolAddress at context creation)
+    JobParams p;
+    fill_job(ctx, desc, out, p);
+    if (p.n_items == 0) return RTAMD_OK;
+    p.queues = ptr;
+    p.n_queues = STATIC_QUEUES;
+    p.queue_stride = STATIC_QUEUE_STRIDE;
+    p.queue_block = ctx->queue_block_fused;
+    p.dyn_thresh = ctx->dyn_thresh_fused; p.dyn_auto = 0; p.dyn_incoherent = ctx->dyn_incoherent;
+    p.stats_prev = nullptr; p.stats_cur = nullptr;   // no coherence feedback: the re-fill threshold is the context's fixed one
+    p.leaf_thresh = ctx->leaf_thresh;
+    p.shadow_anyhit = ctx->shadow_anyhit ? 1u : 0u;
+    p.spill = ptr + STATIC_QUEUE_WORDS;
+    p.spill_wave_words = STATIC_SPILL_ENTRIES * 64u;
+#ifdef RTAMD_EXP_STAMPS
+    p.stamps = nullptr;
+#endif
+    hipStream_t st = ctx->stream;
+    // the array keeps the previous call's contents: the counters must start at zero (the stack columns need no clearing:
+    // an entry is written before it is read)
+    HIP_TRY(ctx, hipMemsetAsync(ptr, 0, STATIC_QUEUE_WORDS * sizeof(uint32_t), st));
+    const SceneDev &s = ctx->sdev;
+    const bool mat = s.materials != nullptr, count = out->counts != nullptr;
+    int per_cu = ctx->persistent_blocks_per_cu[(mat ? 4 : 0) + (count ? 1 : 0)];
+    if (ctx->max_blocks_per_cu && (int)ctx->max_blocks_per_cu < per_cu) per_cu = (int)ctx->max_blocks_per_cu;
+    uint32_t grid = (uint32_t)(ctx->num_cu * per_cu);
+    const uint32_t need = (p.n_items + (BLOCK / 64) - 1) / (BLOCK / 64), cap = STATIC_WAVES / (BLOCK / 64);
+    if (grid > need) grid = need;
+    if (grid > cap) grid = cap;     // the stack columns exist for STATIC_WAVES waves
+    if (grid < 1) grid = 1;
+    if (mat) {
+        if (count) hipLaunchKernelGGL((k_persistent<MODE_FUSED, true, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
+        else hipLaunchKernelGGL((k_persistent<MODE_FUSED, false, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
+    } else {
+        if (count) hipLaunchKernelGGL((k_persistent<MODE_FUSED, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
+        else hipLaunchKernelGGL((k_persistent<MODE_FUSED, false>), dim3(grid), dim3(BLOCK), 0, st, s, p);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    if (out->rgba8) {
+        const uint32_t n_tiles = n_tiles_of(desc->width, desc->height, nullptr);
+        const uint64_t n_out = desc->tile_world == 1 ? (uint64_t)desc->width * desc->height
+                                                     : (uint64_t)local_tiles(n_tiles, desc->tile_rank, desc->tile_world) * RTAMD_TILE_PIXELS;
+        return rtamd_display_rgba8_device(ctx, out->rgba32f, n_out, out->rgba8);
+    }
+    return RTAMD_OK;
+}
+
 int rtamd_render(rtamd_context *ctx, const rtamd_frame_desc *desc, const rtamd_frame_out *out) {
     int rc = check_frame(ctx, desc, out);
     if (rc) return rc;
-    if ((rc = ensure_ctx_device(ctx))) return rc;
+    DeviceScope dev_scope;
+    if ((rc = dev_scope.enter(ctx))) return rc;
     const size_t n_px = (size_t)desc->width * desc->height;
     uint32_t n_tiles = n_tiles_of(desc->width, desc->height, nullptr);
     const size_t n_out = desc->tile_world == 1 ? n_px : (size_t)local_tiles(n_tiles, desc->tile_rank, desc->tile_world) * RTAMD_TILE_PIXELS;

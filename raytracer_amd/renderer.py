@@ -184,6 +184,14 @@ class HipRayTracer:
         o = _ffi.FrameOut(rgba_ptr or None, hit_id_ptr or None, hit_t_ptr or None, counts_ptr or None, rgba8_ptr or None)
         self._check(self._lib.rtamd_render_device(self._h, ctypes.byref(d), ctypes.byref(o)))
 
+    def render_device_static(self, width, height, dir_ptr=0, org_ptr=0, camera=None, has_tex_coords=False, has_normals=False,
+                             tile_rank=0, tile_world=1, rgba_ptr=0, hit_id_ptr=0, hit_t_ptr=0, counts_ptr=0, rgba8_ptr=0):
+        """rtamd_render_device_static: render_device for callers that cannot allocate (static launch scratch)."""
+        d = self._frame_desc(width, height, ctypes.c_void_p(dir_ptr or None) if dir_ptr else None,
+                             ctypes.c_void_p(org_ptr) if org_ptr else None, camera, has_tex_coords, has_normals, tile_rank, tile_world)
+        o = _ffi.FrameOut(rgba_ptr or None, hit_id_ptr or None, hit_t_ptr or None, counts_ptr or None, rgba8_ptr or None)
+        self._check(self._lib.rtamd_render_device_static(self._h, ctypes.byref(d), ctypes.byref(o)))
+
     # ---- split-pipeline trace --------------------------------------------
     def trace(self, org, dir):
         org = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
