@@ -26,8 +26,9 @@ def mixed_material_mask(hit_id, mat_idx, h, w, block=4):
     lacks GL_EXT_nonuniform_qualifier, so the reference shader's
     modelTextures[triangles[i].matIdx] (ray_trace_and_shade.frag:221) is indexed with a
     non-dynamically-uniform value there — undefined by GLSL 4.60; llvmpipe uses one
-    lane's index for the whole 4x4 fragment block.  Such pixels are excluded from
-    colour comparison against llvmpipe (and counted)."""
+    lane's index for the whole 4x4 fragment block.  Kept to DOCUMENT that behaviour
+    (test_oracle_golden.py): the parity assertions use reference_colour(), which is
+    defined on every pixel."""
     hit = hit_id != 0xFFFFFFFF
     mat = np.where(hit, mat_idx[np.minimum(hit_id, len(mat_idx) - 1)], 255).reshape(h, w)
     mask = np.zeros((h, w), bool)
@@ -37,6 +38,14 @@ def mixed_material_mask(hit_id, mat_idx, h, w, block=4):
             if len(set(np.unique(blk)) - {255}) > 1:
                 mask[y0:y0 + block, x0:x0 + block] = True
     return mask.reshape(-1)
+
+
+def reference_colour(g):
+    """The reference colour for EVERY pixel of a fixture: b_fused_uniform where the scene has two textures (the
+    unmodified shader run on llvmpipe once per image with that image bound to both sampler slots, composited by
+    the hit triangle's matIdx — make_golden.py:fused_uniform; the shader's non-uniform sampler index is then
+    immaterial, so mixed-material blocks are defined too), else b_fused."""
+    return (g["b_fused_uniform"] if "b_fused_uniform" in g else g["b_fused"]).reshape(-1, 4)
 
 
 def rgb_err_255(a, b):
@@ -87,7 +96,8 @@ def atrium_golden():
     camera = host.Camera(16 / 9, fov=math.radians(cam["fov_deg"]), position=cam["position"], direction=d)
     dirs, orgs = camera.primary_rays(w, h)
     return {"scene": sc, "dir": dirs, "org": orgs, "tex0": scenes.checker_texture(), "tex1": scenes.noise_texture(),
-            "b_trace": g["b_trace"].reshape(-1, 4), "b_fused": g["b_fused"].reshape(-1, 4), "w": w, "h": h}
+            "b_trace": g["b_trace"].reshape(-1, 4), "b_fused": g["b_fused"].reshape(-1, 4),
+            "b_fused_uniform": g["b_fused_uniform"].reshape(-1, 4), "w": w, "h": h}
 
 
 def soup_golden():

@@ -10,6 +10,8 @@ inputs + outputs as compressed .npz files:
            dir / org ray arrays (h, w, 3; row 0 = bottom), tex0 / tex1 RGB8
   outputs  b_trace  (h, w, 4)  ray_trace/ray_trace.frag   -> (t, u, v, bits(idx))
            b_fused  (h, w, 4)  ray_trace_and_shade.frag   -> fragCol
+           b_fused_uniform (h, w, 4)  the same shader with one image bound to both sampler slots, once per image,
+                    composited per pixel by the hit triangle's matIdx: defined colour for every pixel (f16, atrium)
            b_trace_rand (n, 1, 4) same shader on incoherent rays (secondary-ray stand-in)
   golden_dispatch.npz: ray_trace/ray_dispatcher.frag on a G-buffer (positions, flat normals,
            material bits / 1e30 "no surface") derived from the bunny frame, a seeded 64x64
@@ -21,7 +23,7 @@ inputs + outputs as compressed .npz files:
   golden_raycreate.npz: ray_trace/ray_create.frag for three cameras (inputs + RGB32F direction target)
   golden_soup.npz: the same as golden_atrium for a 100 000-triangle seeded soup (camera frame + 8192 random rays)
 
-The fixtures are data only.  Usage:  python tests/golden/make_golden.py [--only-atrium | --only-soup | --only-raycreate]
+The fixtures are data only.  Usage:  python tests/golden/make_golden.py [--only-atrium | --only-soup | --only-raycreate | --add-uniform]
 """
 import math
 import os
@@ -69,6 +71,45 @@ def random_rays(pos, n, seed):
     return org.reshape(n, 1, 3), d.reshape(n, 1, 3)
 
 
+def fused_uniform(B, sc, dirs, orgs, has_tc, has_n, tex0, tex1, b_trace):
+    """Reference colour for EVERY pixel, mixed-material blocks included.  llvmpipe has no
+    GL_EXT_nonuniform_qualifier, so modelTextures[triangles[i].matIdx] (ray_trace_and_shade.frag:221) takes one
+    lane's index for a whole 4x4 fragment block — undefined behaviour by GLSL 4.60, visible where two materials
+    meet.  With the SAME image bound to both sampler slots the index no longer matters and the unmodified shader's
+    output is defined everywhere: one pass with (tex0, tex0), one with (tex1, tex1), and each pixel is taken from
+    the pass that bound its own material's image (matIdx of the triangle the pixel hit; sky pixels agree in both)."""
+    pass0, _ = B.fused(sc, dirs, orgs, has_tc, has_n, tex0, tex0)
+    pass1, _ = B.fused(sc, dirs, orgs, has_tc, has_n, tex1, tex1)
+    idx = np.ascontiguousarray(b_trace[..., 3]).view(np.uint32)
+    hit = b_trace[..., 0] < 1000.0                                   # the fused shader's hit test, :206
+    mat = np.where(hit, sc["triangles"]["mat_idx"][np.minimum(idx, len(sc["triangles"]) - 1)] & 1, 0)
+    assert np.array_equal(pass0[~hit], pass1[~hit])
+    return np.where((mat == 1)[..., None], pass1, pass0).astype(np.float32)
+
+
+def add_uniform_to_existing():
+    """Adds b_fused_uniform to the committed golden_f16.npz / golden_atrium.npz without touching their other arrays."""
+    from common import atrium_golden
+    B = OracleB()
+    path = os.path.join(HERE, "golden_f16.npz")
+    g = dict(np.load(path, allow_pickle=False))
+    sc = {"nodes": g["nodes"], "triangles": g["triangles"], "positions": g["positions"], "tex_coords": g["tex_coords"], "normals": g["normals"]}
+    again, _ = B.fused(sc, g["dir"], g["org"], bool(g["has_tex_coords"]), bool(g["has_normals"]), g["tex0"], g["tex1"])
+    assert np.array_equal(again.view(np.uint32), g["b_fused"].view(np.uint32)), "llvmpipe no longer reproduces the committed b_fused"
+    g["b_fused_uniform"] = fused_uniform(B, sc, g["dir"], g["org"], bool(g["has_tex_coords"]), bool(g["has_normals"]), g["tex0"], g["tex1"], g["b_trace"])
+    np.savez_compressed(path, **g)
+    diff = np.abs(np.clip(g["b_fused_uniform"], 0, 1) - np.clip(g["b_fused"], 0, 1))[..., :3].max(-1) * 255 > 1
+    print(f"f16: b_fused_uniform differs from b_fused (> 1/255) on {int(diff.sum())} of {diff.size} pixels")
+    a = atrium_golden()
+    path = os.path.join(HERE, "golden_atrium.npz")
+    g = dict(np.load(path, allow_pickle=False))
+    h, w = a["h"], a["w"]
+    g["b_fused_uniform"] = fused_uniform(B, a["scene"], a["dir"], a["org"], True, True, a["tex0"], a["tex1"], g["b_trace"].reshape(h, w, 4))
+    np.savez_compressed(path, **g)
+    diff = np.abs(np.clip(g["b_fused_uniform"], 0, 1) - np.clip(g["b_fused"].reshape(h, w, 4), 0, 1))[..., :3].max(-1) * 255 > 1
+    print(f"atrium: b_fused_uniform differs from b_fused (> 1/255) on {int(diff.sum())} of {diff.size} pixels")
+
+
 def main():
     B = OracleB()
     print("oracle B:", B.renderer)
@@ -105,6 +146,7 @@ def main():
             out["normals"] = sc["normals"]
         if tex0 is not None:
             out["tex0"], out["tex1"] = tex0, tex1
+            out["b_fused_uniform"] = fused_uniform(B, sc, dirs, orgs, model.has_tex_coords(), model.has_normals(), tex0, tex1, b_trace)
         path = os.path.join(HERE, f"golden_{name}.npz")
         np.savez_compressed(path, **out)
         hits = int((b_trace[..., 0] < 1e30).sum())
@@ -185,8 +227,9 @@ def atrium():
     b_fused, _ = B.fused(sc, dirs, orgs, True, True, tex0, tex1)
     digest = hashlib.sha256(b"".join(np.ascontiguousarray(sc[k]).tobytes() for k in ("nodes", "triangles", "positions", "tex_coords", "normals"))).hexdigest()
     path = os.path.join(HERE, "golden_atrium.npz")
-    np.savez_compressed(path, width=np.int32(w), height=np.int32(h), b_trace=b_trace, b_fused=b_fused, scene_sha256=np.array(digest),
-                        renderer=np.array(B.renderer))
+    b_uniform = fused_uniform(B, sc, dirs, orgs, True, True, tex0, tex1, b_trace)
+    np.savez_compressed(path, width=np.int32(w), height=np.int32(h), b_trace=b_trace, b_fused=b_fused, b_fused_uniform=b_uniform,
+                        scene_sha256=np.array(digest), renderer=np.array(B.renderer))
     print(f"atrium: {len(sc['triangles'])} tris, {int((b_trace[..., 0] < 1e30).sum())}/{w * h} hit pixels -> {os.path.getsize(path) / 1e6:.2f} MB")
 
 
@@ -236,7 +279,9 @@ def raycreate():
 
 
 if __name__ == "__main__":
-    if "--only-raycreate" in sys.argv:
+    if "--add-uniform" in sys.argv:
+        add_uniform_to_existing()
+    elif "--only-raycreate" in sys.argv:
         raycreate()
     elif "--only-atrium" in sys.argv:
         atrium()
