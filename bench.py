@@ -6,19 +6,24 @@ A step is one frame of the fused hot path (ray_trace_and_shade.frag semantics):
 for every pixel one primary closest-hit traversal, for every hit pixel normal /
 uv interpolation, one sun shadow traversal, one bilinear texture fetch and the
 Phong/sky shading, RGBA32F out.  Rays (dir/org, 24 B per pixel), scene and
-textures are resident in HBM before the timed region.  With N > 1 ranks the
-frame is split into interleaved 32x32 tiles (scene replicated), every rank
-renders its tiles (RGBA32F, as on one GPU) and converts them with the display pass
-(util/display.frag: float -> 8-bit back buffer), one RCCL gather per 4 frames brings
-the RGBA8 shares to rank 0, which assembles the scan-line frames — all inside the
-timed steps.  (--gather-format f32 moves the float shares instead: 33 MB per frame is
-138 GB/s at this frame rate, more than an xGMI link carries.)
+textures are resident in HBM before the timed region.
 
-Frames in flight (default 4, 8 with N > 1): consecutive frames are issued round-robin on HIP
-streams (the library keeps per-stream launch scratch, include/rtamd.h), each into
-its own output buffer, so the slow tail of frame k overlaps the start of frame
-k+1 — how a real-time renderer submits frames.  All K frames complete inside the
-timed region.  `--frames-in-flight 1` gives the strictly serial number.
+Frames are submitted in batches (rtamd_render_batch_device, default 8 frames per
+launch on one GPU): the persistent kernel pulls the work items of all frames of a
+batch from one queue, so the slow tail of a frame overlaps the next frame's items —
+how a real-time renderer keeps frames in flight — with ONE launch per batch on ONE
+stream and the box's default hardware-queue count.  Launches do not overlap, so the
+HIP-event duration of a launch divided by its frames IS the time per frame that the
+roofline figures use.  `--batch 1` is the strictly serial number (one frame per launch).
+
+With N > 1 ranks the frame is split into interleaved 32x32 tiles (scene replicated):
+every rank renders its tiles of G consecutive frames with one launch (RGBA32F, as on one
+GPU), converts them with the display pass (util/display.frag: float -> 8-bit back
+buffer), one RCCL gather per G frames brings the RGBA8 shares to rank 0, which assembles
+the scan-line frames — all inside the timed steps; two batch buffers alternate, so the
+gather of one batch runs beside the rendering of the next.  (--gather-format f32 moves
+the float shares instead: 33 MB per frame is 138 GB/s at this frame rate, more than an
+xGMI link carries.)
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
 """
@@ -34,28 +39,59 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-# Frames in flight need hardware queues of their own: HIP spreads a process's streams over
-# GPU_MAX_HW_QUEUES queues (default 4) and launches on streams that share one do not overlap.
-# Measured (tools/launch_cost.py, one rank's 1/8 share of the frame): 65 us per frame with 4
-# queues / 6 streams, 42 us with 16 queues / 8 streams.  Read by the HIP runtime when it starts;
-# the GPU boxes export 4, so this replaces the value (RTAMD_BENCH_HW_QUEUES overrides, "0" keeps it).
-_hwq = os.environ.get("RTAMD_BENCH_HW_QUEUES", "16")
+# The HIP runtime reads GPU_MAX_HW_QUEUES once, when it starts.  The bench leaves the box's value alone (batched launches
+# need no extra hardware queues); RTAMD_BENCH_HW_QUEUES=<n> sets it for experiments with several streams.
+_hwq = os.environ.get("RTAMD_BENCH_HW_QUEUES", "0")
 if _hwq != "0":
     os.environ["GPU_MAX_HW_QUEUES"] = str(max(1, min(32, int(_hwq))))
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-VALU_PEAK_TOPS = 78.6        # 157.3 TFLOP/s FMA-count
-VALU_NS_PER_WAVE_INSTR = 1.0  # tools/micro/valu_ops.hip on MI355X: v_mul/v_sub/v_mov, and the visit's mix of classes
-N_SIMDS = 1024               # 256 CUs x 4ed fp32 vector = 78.6 T un-fused op/s
+# Peaks (/opt/skills/guides/MI355X_MICROARCH.md): HBM3E 8 TB/s; fp32 vector 157.3 TFLOP/s counts an FMA as two, and the
+# path may not fuse (bit-exactness), so 78.6 T un-fused op/s; one wave64 VALU instruction issues in 2 cycles per SIMD-32:
+# 1024 SIMDs x 2.4 GHz / 2 = 1228.8 G wave-instructions/s (tools/micro/valu_ops.hip sustains 1.0 ns per instruction
+# per SIMD = 1024 G/s under load); the L1 (TCP) looks up one cache line per clock and CU: 256 x 2.4 GHz = 614.4 G/s.
+HBM_PEAK_GBS = 8000.0
+VALU_PEAK_TOPS = 78.6
+VALU_ISSUE_PEAK_GINST = 1228.8
+TCP_ACCESS_PEAK_G = 614.4
 
 
-WORKLOAD_NOTE = {"atrium_1080p": "procedural Sponza-class atrium", "atrium_small": "procedural Sponza-class atrium",
+WORKLOAD_NOTE = {"f16_640x480": "res/models/f16.obj + F16s.bmp / F16t.bmp (BASELINE config 1, the reference's default scene)",
+                 "atrium_1080p": "procedural Sponza-class atrium", "atrium_small": "procedural Sponza-class atrium",
                  "soup_10m_4k": "seeded triangle soup (BASELINE config 4)", "soup_1m_4k": "seeded triangle soup",
                  "bunny_1080p": "bunny subdivided twice (BASELINE config 2)"}
 
 
+class _FixtureModel:
+    """A committed fixture's scene as uploaded (BVH already built by the host layer when the fixture was made)."""
+
+    def __init__(self, g):
+        self._sc = {"nodes": g["nodes"], "triangles": g["triangles"], "positions": g["positions"],
+                    "tex_coords": g["tex_coords"] if "tex_coords" in g else None, "normals": g["normals"] if "normals" in g else None}
+
+    def scene_arrays(self):
+        return self._sc
+
+    def has_tex_coords(self):
+        return self._sc["tex_coords"] is not None
+
+    def has_normals(self):
+        return self._sc["normals"] is not None
+
+    def build_bvh(self, threads=1):
+        pass
+
+
 def build_workload(name):
     from raytracer_amd import host, scenes
+    if name == "f16_640x480":
+        # BASELINE config 1: the reference's default scene (src/main.rs:30, f16.obj with its two BMP textures) from the
+        # committed fixture, at the config's 640x480, with the fixture's camera (the 160x120 llvmpipe frame is this
+        # camera at a quarter of the resolution: tests/test_host_layer.py checks the rays)
+        z = np.load(os.path.join(REPO, "tests", "golden", "golden_f16.npz"), allow_pickle=False)
+        model = _FixtureModel(z)
+        w, h = 640, 480
+        eye, d, fov = scenes.framing_camera(z["positions"], 0.55)
+        return model, host.Camera(w / h, fov=fov, position=eye, direction=d), w, h, (z["tex0"], z["tex1"])
     if name == "atrium_1080p":
         tri, pos, uv, nrm, cam = scenes.atrium()
         model = host.Model.from_arrays(tri, pos, uv, nrm)
@@ -102,12 +138,15 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="atrium_1080p")
-    ap.add_argument("--variant", type=int, default=0, help="0 persistent (default), 1 static A/B baseline")
-    ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="frames issued round-robin on that many streams (1 = serial; 0 = auto: 4 on one GPU, 8 with tiles split over "
-                         "several GPUs, where a launch covers 1/N of the frame and is bounded by its slowest rays, not by throughput)")
+    ap.add_argument("--variant", type=int, default=0, help="0 persistent (default), 1 static A/B baseline (always one frame per launch)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="frames per launch (rtamd_render_batch_device), 1..8; 1 = one frame at a time.  0 = auto: 8 on one GPU "
+                         "(2 when the scene records exceed the 256 MB Infinity Cache); with N > 1 the frames of one gather")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="one GPU: batches alternate over that many streams (0 = auto: 2, so that the tail of one batch runs beside the "
+                         "start of the next; 1: launches never overlap)")
     ap.add_argument("--gather-batch", type=int, default=0,
-                    help="N > 1: frames per RCCL gather (0 = auto: 4 up to 1080p, 1 above)")
+                    help="N > 1: frames per RCCL gather = frames per launch (0 = auto: 8 up to 1080p, 2 above)")
     ap.add_argument("--gather-format", choices=("f32", "rgba8"), default="rgba8",
                     help="N > 1: what crosses xGMI. rgba8 (default) = the display pass's 8-bit back buffer (util/display.frag) that "
                          "every rank produces from its RGBA32F share; f32 = the RGBA32F shares themselves: 33 MB per 1080p frame, "
@@ -165,57 +204,79 @@ def main():
 
     per_rank_tiles = tracer.tiles_per_rank(W, H, world)
     n_local_out = n_px if world == 1 else per_rank_tiles * TILE_PIXELS
-    # auto: 4 frames in flight on one GPU (8 with N > 1, where a launch covers 1/N of the frame and is bounded by
-    # its slowest rays); 2 when the scene records exceed the 256 MB Infinity Cache, where more frames in
-    # flight only evict each other's nodes (10 M soup: 4.04 ms with 2, 4.30 ms with 4)
     info = tracer.scene_info()
     scene_mb = (info.inner_node_count * 64 + info.triangle_count * 48) / 1e6
-    F = args.frames_in_flight if args.frames_in_flight > 0 else (2 if scene_mb > 256 else 4 if world == 1 else 8)
-    F = max(1, min(8, F))
-    # One GPU: frame k renders on render_streams[k % F] into rgba[k % F].
-    # N > 1: frames are gathered in batches of G (one collective per G frames: the call costs the root's host
-    # 13+ us, a third of the 39 us a 1/8 share of this frame takes).  Batch j = frames jG .. jG+G-1 renders on
-    # render_streams[j % F], back to back, into batch buffer j % F ([G][n_local_out] pixels); `stream` then waits
-    # for that stream, gathers the buffer, assembles the G scan-line frames and marks the buffer free.
-    G = 1
+    # Frames per launch.  One GPU: 8 (2 when the scene records exceed the 256 MB Infinity Cache, where more frames in flight
+    # only evict each other's nodes).  N > 1: the frames of one gather (one collective per G frames: the call costs the root's
+    # host 13+ us, a third of the time a 1/8 share of this frame takes; and a launch over one share of ONE frame is bounded by its
+    # slowest pixel, not by throughput).
     if world > 1:
-        G = args.gather_batch if args.gather_batch > 0 else (4 if n_px <= 1920 * 1080 else 1)
-    render_streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(F - 1)]
-    rgba = [torch.zeros((G * n_local_out, 4), dtype=torch.float32, device=dev) for _ in range(F)]
-    consumed = [torch.cuda.Event() for _ in range(F)]   # batch buffer f has been gathered
+        # measured on one GPU (tools/share_cost.py: a rank's 1/8 share of this frame, render + display pass, two alternating streams):
+        # 134 us per frame with one frame per launch, 52 us with 4, 37 us with 8
+        B = args.gather_batch if args.gather_batch > 0 else (args.batch if args.batch > 0 else (8 if n_px <= 1920 * 1080 else 2))
+    else:
+        B = args.batch if args.batch > 0 else (2 if scene_mb > 256 else 8)
+    B = max(1, min(8, B))
+    if args.variant != 0:
+        B = 1
+    # Batch j = frames jB .. jB+B-1 renders with one launch on render_streams[j % S] into batch buffer j % S ([B][n_local_out]
+    # pixels).  N > 1: `stream` then waits for that stream, converts (rgba8), gathers the buffer, assembles the B scan-line
+    # frames and marks the buffer free, while the next batch renders on the other stream.
+    S = (max(1, min(4, args.streams)) if args.streams > 0 else (2 if args.variant == 0 else 1)) if world == 1 else 2
+    render_streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
+    rgba = [torch.zeros((B * n_local_out, 4), dtype=torch.float32, device=dev) for _ in range(S)]
+    consumed = [torch.cuda.Event() for _ in range(S)]   # batch buffer f has been gathered
     d_rgba = rgba[0]
-    if F == 2 and world == 1:
-        # two streams that share a hardware queue cannot overlap: try a handful of partner streams and keep
-        # the one that overlaps best (only matters when GPU_MAX_HW_QUEUES is left at a small value)
-        def pair_ms(partner, frames=16):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for k in range(frames):
-                tracer.set_stream((stream, partner)[k % 2].cuda_stream)
-                tracer.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=has_tc, has_normals=has_n,
-                                     tile_rank=rank, tile_world=world, rgba_ptr=rgba[k % 2].data_ptr())
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / frames
-        candidates = [render_streams[1]] + [torch.cuda.Stream(device=dev) for _ in range(3)]
-        for c in candidates:
-            pair_ms(c, 4)   # first use of a stream creates its queue
-        render_streams[1] = min(candidates, key=pair_ms)
-        tracer.set_stream(stream.cuda_stream)
     frame = None
     as8 = world > 1 and args.gather_format == "rgba8"
     send = rgba
     if as8:   # each rank also writes its share as the display pass would (8-bit back buffer); the gather moves that
-        send = [torch.zeros((G * n_local_out,), dtype=torch.int32, device=dev) for _ in range(F)]
+        send = [torch.zeros((B * n_local_out,), dtype=torch.int32, device=dev) for _ in range(S)]
     if world > 1 and rank == 0:
         if as8:
-            gathered = torch.empty((world, G * n_local_out), dtype=torch.int32, device=dev)
-            frames_out = torch.empty((G, n_px), dtype=torch.int32, device=dev)
+            gathered = torch.empty((world, B * n_local_out), dtype=torch.int32, device=dev)
+            frames_out = torch.empty((B, n_px), dtype=torch.int32, device=dev)
         else:
-            gathered = torch.empty((world, G * n_local_out, 4), dtype=torch.float32, device=dev)   # [rank][frame of the batch][pixel]
-            frames_out = torch.empty((G, n_px, 4), dtype=torch.float32, device=dev)
+            gathered = torch.empty((world, B * n_local_out, 4), dtype=torch.float32, device=dev)   # [rank][frame of the batch][pixel]
+            frames_out = torch.empty((B, n_px, 4), dtype=torch.float32, device=dev)
         frame = frames_out[0]
-    launch_events = []
-    pending = [None]   # batch buffer that holds rendered frames not gathered yet
+    launch_events = []     # (frames in the launch, start event, stop event)
+    if S == 2 and world == 1:
+        # two streams that share a hardware queue cannot overlap (HIP spreads a process's streams over GPU_MAX_HW_QUEUES
+        # queues): try a handful of partner streams and keep the one that overlaps best with the main stream
+        def pair_ms(partner, batches=6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(batches):
+                tracer.set_stream((stream, partner)[k % 2].cuda_stream)
+                tracer.render_batch_device(W, H, [{"dir_ptr": d_dir.data_ptr(), "org_ptr": d_org.data_ptr(), "rgba_ptr": rgba[k % 2].data_ptr() + g * n_local_out * 16}
+                                                  for g in range(B)], has_tex_coords=has_tc, has_normals=has_n)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / batches
+        candidates = [render_streams[1]] + [torch.cuda.Stream(device=dev) for _ in range(3)]
+        for c in candidates:
+            pair_ms(c, 2)   # first use of a stream creates its queue
+        render_streams[1] = min(candidates, key=pair_ms)
+        tracer.set_stream(stream.cuda_stream)
+
+    def launch(f, n_frames, timed):
+        """Frames 0..n_frames-1 of batch buffer f in ONE launch on render_streams[f]."""
+        rs = render_streams[f]
+        tracer.set_stream(rs.cuda_stream)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(rs)
+        kw = dict(has_tex_coords=has_tc, has_normals=has_n, tile_rank=rank, tile_world=world)
+        if n_frames == 1:
+            tracer.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), rgba_ptr=rgba[f].data_ptr(), **kw)
+        else:
+            tracer.render_batch_device(W, H, [{"dir_ptr": d_dir.data_ptr(), "org_ptr": d_org.data_ptr(), "rgba_ptr": rgba[f].data_ptr() + g * n_local_out * 16}
+                                              for g in range(n_frames)], **kw)
+        if timed:
+            e1.record(rs)
+            launch_events.append((n_frames, e0, e1))
+        if as8:   # the display pass over the whole batch buffer, behind the render on the same stream
+            tracer.display_rgba8_device(rgba[f].data_ptr(), n_frames * n_local_out, send[f].data_ptr())
 
     def flush(f):
         """Gather batch buffer f (all ranks call this at the same step) and assemble its frames on the root."""
@@ -235,34 +296,26 @@ def main():
             dist.gather(send[f], dst=0)
         if rank == 0:
             tracer.set_stream(stream.cuda_stream)
-            tracer.assemble_tile_batch_device(gathered.data_ptr(), W, H, world, 1 if as8 else 4, G, frames_out.data_ptr())
+            tracer.assemble_tile_batch_device(gathered.data_ptr(), W, H, world, 1 if as8 else 4, B, frames_out.data_ptr())
         consumed[f].record(stream)
-        pending[0] = None
 
-    def step(k, timed=False):
-        batch, g = divmod(k, G)
-        f = batch % F
-        rs = render_streams[f]
-        if world > 1 and g == 0 and batch >= F:
-            rs.wait_event(consumed[f])          # the buffer is free again once batch - F has been gathered
-        tracer.set_stream(rs.cuda_stream)
-        # launch durations for the roofline: every launch on one GPU; with N > 1 the host has ~40 us per step
-        # for everything (render call, gather, assembly), so only every 8th launch carries the two extra events
-        timed = timed and (world == 1 or k % 8 == 0)
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(rs)
-        # with the RGBA8 gather the kernel writes the display-format pixel beside the float one (rtamd_frame_out.rgba8)
-        tracer.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=has_tc, has_normals=has_n,
-                             tile_rank=rank, tile_world=world, rgba_ptr=rgba[f].data_ptr() + g * n_local_out * 16,
-                             rgba8_ptr=(send[f].data_ptr() + g * n_local_out * 4) if as8 else 0)
-        if timed:
-            e1.record(rs)
-            launch_events.append((e0, e1))
-        if world > 1:
-            pending[0] = f
-            if g == G - 1:
+    def run(n_steps, timed=False):
+        """n_steps frames: full batches of B, then one smaller batch for the rest; every frame is rendered (and, N > 1,
+        gathered and assembled) by the time the streams are joined."""
+        done, batch = 0, 0
+        while done < n_steps:
+            nf = min(B, n_steps - done)
+            f = batch % S
+            if world > 1 and batch >= S:
+                render_streams[f].wait_event(consumed[f])      # the buffer is free again once batch - S has been gathered
+            launch(f, nf, timed)
+            if world > 1:
                 flush(f)
+            done += nf
+            batch += 1
+        for rs in render_streams:
+            if rs is not stream:
+                stream.wait_stream(rs)
 
     # ---- untimed: per-pixel counters of the whole frame (rank-local share) for the roofline
     d_counts = torch.zeros((n_local_out, 2), dtype=torch.int32, device=dev)
@@ -293,10 +346,7 @@ def main():
     # ---- warmup + timed region
     tracer.set_stream(stream.cuda_stream)
     torch.cuda.synchronize()
-    for k in range(args.warmup):
-        step(k)
-    if pending[0] is not None:
-        flush(pending[0])
+    run(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -304,13 +354,7 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t_start = time.perf_counter()
     ev0.record(stream)
-    for k in range(args.steps):
-        step(k, timed=True)
-    if pending[0] is not None:
-        flush(pending[0])       # the last, partial batch: all K frames are gathered and assembled inside the timed region
-    for rs in render_streams:
-        if rs is not stream:
-            stream.wait_stream(rs)
+    run(args.steps, timed=True)
     ev1.record(stream)
     torch.cuda.synchronize()
     if world > 1:
@@ -323,15 +367,31 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed, ev_ms = float(tt[0]), float(tt[1])
 
-    # ---- duration of the dominant kernel's launches: HIP events on the launch stream around every
-    # timed launch (with frames in flight the launches overlap, so this exceeds ms_per_step)
-    kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in launch_events]))
+    # ---- duration of the dominant kernel's launches: HIP events on the launch stream around every launch.  In the timed
+    # region batches alternate over S streams and their launches overlap, so those spans say nothing about one launch
+    # (they are kept as `overlapped_launch_ms`); the figure the roofline uses comes from launches that do NOT overlap:
+    # after the timed region, the same batches back to back on one stream (what `--streams 1` runs, and what the committed
+    # rocprofv3 --kernel-trace --stats summary of `--streams 1` shows as the kernel's average duration).
+    full = [e0.elapsed_time(e1) for nf, e0, e1 in launch_events if nf == B]
+    if not full:
+        full = [e0.elapsed_time(e1) * B / nf for nf, e0, e1 in launch_events]
+    overlapped_launch_ms = float(np.mean(full))
+    launch_ms = overlapped_launch_ms
+    n_alone = 0
+    if S > 1 and world == 1:
+        launch_events.clear()
+        n_alone = max(5, min(60, args.steps // B))
+        torch.cuda.synchronize()
+        for _ in range(n_alone):
+            launch(0, B, True)
+        torch.cuda.synchronize()
+        launch_ms = float(np.mean([e0.elapsed_time(e1) for nf, e0, e1 in launch_events]))
+    frame_ms_in_launch = launch_ms / B
     tracer.set_stream(stream.cuda_stream)
 
-    # ---- untimed extra for the record: the same frame one at a time (what a caller that waits for every frame
-    # sees); `value` and `ms_per_step` above are the pipelined figures
+    # ---- untimed extra for the record: the same frame one at a time (what a caller that waits for every frame sees)
     serial_ms = None
-    if world == 1 and F > 1:
+    if world == 1 and B > 1:
         n_serial = max(10, min(200, args.steps))
         torch.cuda.synchronize()
         s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -349,30 +409,79 @@ def main():
 
     frame_check = None
     if world > 1:
-        # untimed: the assembled frame of the last step must equal this rank rendering the whole frame alone
-        full = torch.zeros((n_px, 4), dtype=torch.float32, device=dev)
-        tracer.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=has_tc, has_normals=has_n, rgba_ptr=full.data_ptr())
+        # untimed: the assembled frames of the last batch must equal this rank rendering the whole frame alone
+        whole = torch.zeros((n_px, 4), dtype=torch.float32, device=dev)
+        tracer.render_device(W, H, d_dir.data_ptr(), d_org.data_ptr(), has_tex_coords=has_tc, has_normals=has_n, rgba_ptr=whole.data_ptr())
         torch.cuda.synchronize()
-        n_last = (args.steps - 1) % G + 1      # frames the last gathered batch holds
+        n_last = (args.steps - 1) % B + 1      # frames the last gathered batch holds
         if as8:
-            full8 = torch.zeros((n_px,), dtype=torch.int32, device=dev)
-            tracer.display_rgba8_device(full.data_ptr(), n_px, full8.data_ptr())
+            whole8 = torch.zeros((n_px,), dtype=torch.int32, device=dev)
+            tracer.display_rgba8_device(whole.data_ptr(), n_px, whole8.data_ptr())
             torch.cuda.synchronize()
-            full = full8
-        frame_check = all(bool(torch.equal(full.view(torch.int32).reshape(-1), frames_out[i].view(torch.int32).reshape(-1))) for i in range(n_last))
+            whole = whole8
+        frame_check = all(bool(torch.equal(whole.view(torch.int32).reshape(-1), frames_out[i].view(torch.int32).reshape(-1))) for i in range(n_last))
 
     ms_per_step = elapsed * 1e3 / args.steps
     value = rays_per_frame * args.steps / elapsed / 1e6
 
-    # algorithmic bytes / ops of ONE launch on this rank:
+    # algorithmic bytes / ops of ONE frame on this rank:
     #   36 B per AABB test + 52 B per triangle test + 24 B ray in per ray + 16 B RGBA32F out per pixel
     #   + per shaded pixel 3x12 B normals + 3x8 B uvs + 16 B triangle record + 4 texels x 4 B
     shaded_extra = (36 if has_n else 0) + (24 if has_tc else 0) + 16 + 16
     alg_bytes = 36 * n_box + 52 * n_tri + 24 * (n_primary + n_shadow) + 16 * n_primary + shaded_extra * n_shadow
     alg_ops = 25 * n_box + 60 * n_tri + 150 * n_shadow
-    launch_ms = kernel_ms
-    achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
-    job_ms = ev_ms / args.steps
+    frame_s = frame_ms_in_launch * 1e-3
+    alg_gbs = alg_bytes / frame_s / 1e9
+    valu_tops = alg_ops / frame_s / 1e12
+
+    # Counters of the same kernel on the same workload from the committed rocprofv3 --pmc passes (PMC runs serialise
+    # kernels, so they cannot be collected inside the timed region); the record names the roof that bounds the workload.
+    cpath = os.path.join(REPO, "profiles", f"counters_{args.workload}.json")
+    prof = json.load(open(cpath)) if world == 1 and args.variant == 0 and os.path.exists(cpath) else None
+    roof = {"kernel": "k_persistent<fused>" if args.variant == 0 else "k_static<fused>",
+            "launch": {"frames": B, "ms": round(launch_ms, 5), "ms_per_frame": round(frame_ms_in_launch, 5), "launches_overlap": False if n_alone else S > 1,
+                       "timing": (f"HIP events on the launch stream around {n_alone} launches of {B} frames, back to back on ONE stream after the timed "
+                                  f"region (as `--streams 1`); in the timed region batches alternate over {S} streams and a launch's span is "
+                                  f"{overlapped_launch_ms:.4f} ms beside its neighbour") if n_alone else
+                                 "HIP events on the launch stream around every timed launch of a full batch"},
+            "frac_at_job_rate_note": "every frac here divides by launch.ms_per_frame; at the job's rate multiply by launch.ms_per_frame / ms_per_step",
+            "stream_ms_per_step_hip_events": round(ev_ms / args.steps, 5),
+            "aabb_tests_per_ray": round(n_box / max(1, n_primary + n_shadow), 2),
+            "tri_tests_per_ray": round(n_tri / max(1, n_primary + n_shadow), 2),
+            "valu": {"algorithmic_ops_per_frame": alg_ops, "achieved_Tops": round(valu_tops, 3), "peak_Tops": VALU_PEAK_TOPS,
+                     "frac": round(valu_tops / VALU_PEAK_TOPS, 5), "note": "SURVEY 8d operation count (25 per AABB test, 60 per triangle test, 150 per shaded "
+                     "pixel) over the un-fused fp32 peak"},
+            "hbm": {"algorithmic_bytes_per_frame": alg_bytes, "algorithmic_GBs": round(alg_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
+    if prof:
+        pf = prof["per_frame"]
+        traffic = pf["hbm_bytes"]
+        hbm_gbs = traffic / frame_s / 1e9
+        roof["hbm"].update({"traffic_bytes_per_frame": traffic, "achieved": round(hbm_gbs, 2), "frac": round(hbm_gbs / HBM_PEAK_GBS, 5),
+                            "algorithmic_over_traffic": round(alg_bytes / traffic, 2),
+                            "cache_served": alg_bytes > 2 * traffic,
+                            "note": "traffic = 2 x FETCH_SIZE + WRITE_SIZE of the PMC passes (gfx950 tallies the 128-B requests of wide loads at "
+                                    "64 B); the algorithmic bytes are what the reference's layout would move per test: where they exceed the "
+                                    "traffic, L1 / L2 / Infinity Cache serve them"})
+        inst = pf["valu_wave_instructions"]
+        ginst = inst / frame_s / 1e9
+        roof["valu"].update({"wave_instructions_per_frame": inst, "issue_Ginst_s": round(ginst, 2), "issue_peak_Ginst_s": VALU_ISSUE_PEAK_GINST,
+                             "issue_frac": round(ginst / VALU_ISSUE_PEAK_GINST, 5)})
+        tcp = pf.get("tcp_cache_accesses")
+        if tcp:
+            roof["l1"] = {"tcp_cache_accesses_per_frame": tcp, "achieved_G_s": round(tcp / frame_s / 1e9, 2), "peak_G_s": TCP_ACCESS_PEAK_G,
+                          "frac": round(tcp / frame_s / 1e9 / TCP_ACCESS_PEAK_G, 5)}
+        roof["counters_from"] = prof["source"]
+        if prof.get("bound") == "tcp_access_rate" and tcp:
+            head = {"bound": "l1_access_rate", "achieved": roof["l1"]["achieved_G_s"], "peak": TCP_ACCESS_PEAK_G, "unit": "G cache-line look-ups/s",
+                    "frac": roof["l1"]["frac"]}
+        else:
+            head = {"bound": "valu_issue", "achieved": round(ginst, 2), "peak": VALU_ISSUE_PEAK_GINST, "unit": "G wave64 VALU instructions/s",
+                    "frac": roof["valu"]["issue_frac"]}
+        head["traffic"] = traffic * B      # HBM bytes per launch
+    else:
+        # no counter record for this workload / variant / rank count: price the algorithmic operation count against the VALU roof
+        head = {"bound": "valu", "achieved": round(valu_tops, 3), "peak": VALU_PEAK_TOPS, "unit": "Top/s (un-fused fp32)",
+                "frac": round(valu_tops / VALU_PEAK_TOPS, 5), "traffic": None}
     out = {
         "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -382,37 +491,14 @@ def main():
                                f"{W}x{H}, 1 spp, primary + sun shadow ray + shading (fused ray_trace_and_shade semantics)",
                    "rays_per_frame": rays_per_frame, "primary_rays": n_primary_all, "shadow_rays": n_shadow_all,
                    "parallelism": f"tiles{world}" if world > 1 else "single", "kernel_variant": args.variant,
-                   "frames_in_flight": F, **({"frames_per_gather": G, "gather_format": args.gather_format} if world > 1 else {}),
+                   "frames_per_launch": B, "streams": S, **({"gather_format": args.gather_format} if world > 1 else {}),
                    **({"ms_per_frame_one_at_a_time": round(serial_ms, 5)} if serial_ms is not None else {}), "shadow_rays_stop_at_first_occluder": True,
                    **({"assembled_frame_equals_single_gpu_frame": frame_check} if frame_check is not None else {}),
                    **({"REHEARSAL_not_a_measurement": "all ranks on cuda:0, gloo gather through host memory"} if rehearse else {}),
+                   "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                    "bvh_build_s": round(build_s, 2)},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                     "kernel": "k_persistent<fused>" if args.variant == 0 else "k_static<fused>",
-                     "launch_ms": round(launch_ms, 5), "launches_overlap": F > 1,
-                     "stream_ms_per_step_hip_events": round(job_ms, 5),
-                     "achieved_per_step": round(alg_bytes / (job_ms * 1e-3) / 1e9, 2),
-                     "algorithmic_bytes_per_launch": alg_bytes,
-                     "aabb_tests_per_ray": round(n_box / max(1, n_primary + n_shadow), 2),
-                     "tri_tests_per_ray": round(n_tri / max(1, n_primary + n_shadow), 2),
-                     "valu": {"achieved_Tops": round(alg_ops / (launch_ms * 1e-3) / 1e12, 3), "peak_Tops": VALU_PEAK_TOPS,
-                              "frac": round(alg_ops / (launch_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS, 5)}},
+        "roofline": {**head, **roof},
     }
-
-    # HBM-side traffic of the same kernel from the committed rocprofv3 --pmc passes
-    # (cannot be collected live: PMC runs serialise kernels); see profiles/.
-    tpath = os.path.join(REPO, "profiles", f"traffic_{args.workload}.json")
-    if world == 1 and args.variant == 0 and os.path.exists(tpath):
-        prof = json.load(open(tpath))
-        out["roofline"]["traffic"] = prof["traffic_bytes_per_launch"]
-        if "valu_wave_instructions_per_launch" in prof:
-            # what actually bounds the kernel: VALU issue.  Instructions per launch from the committed PMC pass,
-            # issue rate from the micro-benchmark (1.0 ns per wave64 instruction per SIMD, 1024 SIMDs), over the
-            # time one frame takes in the pipeline
-            busy_ms = prof["valu_wave_instructions_per_launch"] * VALU_NS_PER_WAVE_INSTR * 1e-6 / N_SIMDS
-            out["roofline"]["valu"]["issue_frac"] = round(busy_ms / job_ms, 4)
-            out["roofline"]["valu"]["wave_instructions_per_launch"] = prof["valu_wave_instructions_per_launch"]
 
     if world == 1 and not args.no_cpu_baseline:
         # oracle A (the CPU restatement) on the same frame, bounded: every 2nd pixel row
@@ -420,7 +506,8 @@ def main():
         from oracles import OracleA
         A = OracleA()
         cores = min(16, os.cpu_count() or 1)
-        dirs = d_dir.view(H, W, 3)[::2].contiguous().cpu().numpy().reshape(-1, 3)
+        step_rows = 2 if n_px >= 1920 * 1080 else 1
+        dirs = d_dir.view(H, W, 3)[::step_rows].contiguous().cpu().numpy().reshape(-1, 3)
         orgs = np.broadcast_to(np.asarray(camera.position, np.float32), dirs.shape).copy()
         reps = 12
         tc0 = time.perf_counter()
@@ -429,8 +516,17 @@ def main():
         cpu_s = time.perf_counter() - tc0
         cpu_rays = reps * (len(dirs) + int((r["hit_id"] != 0xFFFFFFFF).sum()))
         out["cpu_baseline"] = {"value": round(cpu_rays / cpu_s / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                               "sample": f"oracle/oracle_a.c, {reps} passes over every 2nd pixel row of the same frame "
+                               "sample": f"oracle/oracle_a.c, {reps} passes over every {'2nd pixel row' if step_rows == 2 else 'pixel'} of the same frame "
                                          f"({len(dirs)} pixels per pass, {cpu_rays} rays in all, {cpu_s:.1f} s wall on {cores} threads)"}
+        # baseline B1: the unmodified reference shader on Mesa llvmpipe.  The shader text does not travel to the
+        # GPU box, so this is the committed record of the build container's run (tools/llvmpipe_baseline.py), not a live figure.
+        lpath = os.path.join(REPO, "profiles", "llvmpipe_baseline.json")
+        if os.path.exists(lpath):
+            rec = json.load(open(lpath)).get(args.workload)
+            if rec:
+                out["cpu_baseline"]["reference_llvmpipe"] = {k: rec[k] for k in ("mrays_per_s", "ms_per_frame", "host_cores", "llvmpipe_threads",
+                                                                                  "renderer", "where", "timing", "shader")}
+                out["cpu_baseline"]["reference_llvmpipe"]["record"] = "profiles/llvmpipe_baseline.json"
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

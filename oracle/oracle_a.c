@@ -441,12 +441,15 @@ int oa_trace(const oa_scene *sc, uint64_t n, const float *org, const float *dir,
     return run_jobs(&j, nthreads);
 }
 
-/* ray_create.frag:12 evaluated at pixel centres (quad-11.vert:8), row 0 = bottom. */
-void oa_raycreate(uint32_t w, uint32_t h, const float *m /* column-major invProjView */, float near_, float far_, float *dir_out) {
+/* ray_create.frag:12 evaluated at (off_x, off_y) inside each pixel, row 0 = bottom.  (0.5, 0.5) is the pixel centre
+ * the reference rasterises (quad-11.vert:8); other offsets are the jittered samples of multi-sample frames, which the
+ * reference does not have (one sample per pixel). */
+void oa_raycreate_offset(uint32_t w, uint32_t h, const float *m /* column-major invProjView */, float near_, float far_,
+                         float off_x, float off_y, float *dir_out) {
     for (uint32_t py = 0; py < h; py++) {
-        float y = ((float)py + 0.5f) / (float)h * 2.0f - 1.0f;
+        float y = ((float)py + off_y) / (float)h * 2.0f - 1.0f;
         for (uint32_t px = 0; px < w; px++) {
-            float x = ((float)px + 0.5f) / (float)w * 2.0f - 1.0f;
+            float x = ((float)px + off_x) / (float)w * 2.0f - 1.0f;
             float v[4] = { x * far_ - x * near_, y * far_ - y * near_, 1.0f * far_ - (-1.0f) * near_, 1.0f * far_ - 1.0f * near_ };
             v3 d;
             float r[3];
@@ -457,6 +460,10 @@ void oa_raycreate(uint32_t w, uint32_t h, const float *m /* column-major invProj
             o[0] = d.x; o[1] = d.y; o[2] = d.z;
         }
     }
+}
+
+void oa_raycreate(uint32_t w, uint32_t h, const float *m, float near_, float far_, float *dir_out) {
+    oa_raycreate_offset(w, h, m, near_, far_, 0.5f, 0.5f, dir_out);
 }
 
 /* ray_trace/ray_dispatcher.frag:26-41 over a w x h G-buffer (row 0 = bottom): secondary-ray

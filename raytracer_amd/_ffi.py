@@ -136,7 +136,7 @@ def host_lib():
     return _host
 
 
-ABI_VERSION = 5   # include/rtamd.h RTAMD_ABI_VERSION
+ABI_VERSION = 6   # include/rtamd.h RTAMD_ABI_VERSION
 
 
 def device_lib():
@@ -178,6 +178,8 @@ def device_lib():
         for name in ("rtamd_render", "rtamd_render_device", "rtamd_render_device_static"):
             getattr(L, name).argtypes = [vp, ctypes.POINTER(FrameDesc), ctypes.POINTER(FrameOut)]
             getattr(L, name).restype = ctypes.c_int
+        L.rtamd_render_batch_device.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(FrameDesc), ctypes.POINTER(FrameOut)]
+        L.rtamd_render_batch_device.restype = ctypes.c_int
         for name in ("rtamd_trace", "rtamd_trace_device"):
             getattr(L, name).argtypes = [vp, ctypes.c_uint64, vp, vp, vp]
             getattr(L, name).restype = ctypes.c_int

@@ -81,6 +81,22 @@ struct SceneDev {
     uint32_t root_ref;
 };
 
+// One frame of a batch (rtamd_render_batch_device): its rays or camera in, its pixels out.
+constexpr int MAX_BATCH_FRAMES = 8;           // RTAMD_MAX_BATCH_FRAMES
+constexpr uint32_t BATCH_FRAME_SHIFT = 28;    // a lane's out_index carries its frame in the top bits: pixels per frame < 2^28
+struct FrameIO {
+    const float *dir, *org;       // nullptr dir => generate from the camera below
+    float *rgba;
+    uint32_t *hit_id;
+    float *hit_t;
+    uint32_t *counts;
+    float ipv[16];
+    float near_, far_;
+    float cam[3];
+    uint32_t pad;
+};
+static_assert(sizeof(FrameIO) == 136, "FrameIO layout");
+
 struct JobParams {
     // fused render
     uint32_t width, height;
@@ -115,6 +131,11 @@ struct JobParams {
     uint32_t queue_block;         // consecutive schedule positions a queue owns per turn
     uint32_t *spill;              // k_persistent: [wave slot][spill_wave_words / 64 entries][64] stack overflow area
     uint32_t spill_wave_words;    // u32 words per wave slot of `spill` (SPILL_STACK_ENTRIES * 64 for the context's own areas)
+    // batch of frames in ONE launch (k_persistent, fused mode): item i belongs to frame i / items_per_frame; frame f's rays,
+    // camera and outputs are frames[f] (the fields above are not used then).  n_frames == 1: the fields above, as ever.
+    uint32_t n_frames;
+    uint32_t items_per_frame;
+    FrameIO frames[MAX_BATCH_FRAMES];
 #ifdef RTAMD_EXP_STAMPS
     unsigned long long *stamps;   // diagnostic build only: per wave {start, end, items, xcc} in 100 MHz ticks
 #endif
@@ -223,7 +244,15 @@ struct StackScratch {
 };
 struct StackGlobal {
     uint32_t *lds;
-    uint32_t *spill;  // this lane's column: entry e at spill[e * 64]
+    // HBM columns: entry e of lane l of the workgroup's wave w sits at spill_base[(w * wave_words) + e * 64 + l].
+    // Only wave-uniform values are kept: the lane's own address is rebuilt from sp's low bits (tid * 4) in the rare
+    // branches that need it, so the column costs no VGPR in the visit loop (a per-lane 64-bit pointer cost two).
+    uint32_t *spill_base;     // the workgroup's first wave slot
+    uint32_t wave_words;
+    __device__ __forceinline__ uint32_t *column(uint32_t sp) const {
+        const uint32_t t = (sp & (STEP - 1u)) >> 2;     // threadIdx.x
+        return spill_base + (size_t)(t >> 6) * wave_words + (t & 63u);
+    }
     static constexpr uint32_t STEP = BLOCK * 4u;
     static constexpr uint32_t RING = LDS_STACK_ENTRIES * STEP;
     static_assert((LDS_STACK_ENTRIES & (LDS_STACK_ENTRIES - 1)) == 0, "ring addressing needs a power-of-two entry count");
@@ -234,7 +263,7 @@ struct StackGlobal {
     __device__ __forceinline__ void push(uint32_t, uint32_t &sp, uint32_t &sb, uint32_t v) {
         if (__builtin_expect(sp - sb >= RING, 0)) {   // ring full: its oldest entry goes to HBM
             const uint32_t e = sb / STEP;
-            if (e < (uint32_t)SPILL_STACK_ENTRIES) spill[e * 64u] = lds_word(sp);   // slot (sp & mask) holds entry sb
+            if (e < (uint32_t)SPILL_STACK_ENTRIES) column(sp)[e * 64u] = lds_word(sp);   // slot (sp & mask) holds entry sb
             sb += STEP;
         }
         lds_word(sp, v);
@@ -245,7 +274,7 @@ struct StackGlobal {
         if (__builtin_expect(sp >= sb, 1)) return lds_word(sp);   // sp - sb carries + tid*4, so >= means "entry sp is in the ring"
         sb -= STEP;                                               // ring empty: the top entry is the last one moved out
         const uint32_t e = sb / STEP;
-        return e < (uint32_t)SPILL_STACK_ENTRIES ? spill[e * 64u] : REF_NONE;
+        return e < (uint32_t)SPILL_STACK_ENTRIES ? column(sp)[e * 64u] : REF_NONE;
     }
 };
 
@@ -593,6 +622,15 @@ __device__ __forceinline__ uint32_t fetch_item(const JobParams &p, uint32_t home
     }
 }
 
+// fragCol = vec4(colour, 1) (:231,233) as one 16-byte store.  The alpha is materialised right here: as a literal the
+// compiler hoists it out of the kernel's main loop as the 4th register of a tuple and then spills and reloads that
+// whole tuple around the traversal (16 bytes of scratch traffic per lane and outer iteration).
+__device__ __forceinline__ void store_frag_col(float *__restrict__ rgba, uint32_t index, float r, float g, float b) {
+    float one;
+    asm volatile("v_mov_b32 %0, 1.0" : "=v"(one));
+    *reinterpret_cast<float4 *>(rgba + 4 * (size_t)index) = make_float4(r, g, b, one);
+}
+
 enum : uint32_t { PH_IDLE = 0, PH_PRIMARY = 1, PH_SHADOW = 2 };   // bits 2..5: (8 | direction octant) << 2 when the octant test applies
 enum : int { MODE_FUSED = 0, MODE_TRACE = 1 };
 __device__ __forceinline__ uint32_t ray_pos_flag(const Ray &r) {
@@ -609,10 +647,23 @@ __device__ __forceinline__ uint32_t ray_pos_flag(const Ray &r) {
 template <int MODE, bool COUNT, bool MAT = false>
 __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(const SceneDev s, const JobParams p) {
     __shared__ uint32_t lds_stack[LDS_STACK_ENTRIES * BLOCK];
+    // fused shader: the in-shadow colour of a lane's pixel waits here ([channel][thread]) while its shadow ray is traced
+    __shared__ float lds_shadow_col[MODE == MODE_FUSED ? 3 * BLOCK : 1];
+    // batch of frames: a lane finds its frame's output buffers here (filled from the kernel arguments below)
+    __shared__ uint64_t lds_frame_out[MODE == MODE_FUSED ? MAX_BATCH_FRAMES : 1][4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (MODE == MODE_FUSED && p.n_frames > 1u) {
+        for (uint32_t f = 0; f < p.n_frames; f++)      // f is wave-uniform: scalar loads of the arguments, one lane stores
+            if (tid == f) {
+                lds_frame_out[f][0] = (uint64_t)(uintptr_t)p.frames[f].rgba;  lds_frame_out[f][1] = (uint64_t)(uintptr_t)p.frames[f].hit_id;
+                lds_frame_out[f][2] = (uint64_t)(uintptr_t)p.frames[f].hit_t; lds_frame_out[f][3] = (uint64_t)(uintptr_t)p.frames[f].counts;
+            }
+        __syncthreads();
+    }
     StackGlobal st;
     st.lds = lds_stack;
-    st.spill = p.spill + (size_t)(blockIdx.x * (BLOCK / 64) + (tid >> 6)) * p.spill_wave_words + lane;
+    st.spill_base = p.spill + (size_t)(blockIdx.x * (BLOCK / 64)) * p.spill_wave_words;
+    st.wave_words = p.spill_wave_words;
 
     // wave-uniform pool of pending pixels / rays: item `pool_item`, lanes [pool_next, 64)
     uint32_t pool_item = 0, pool_next = 64;
@@ -653,9 +704,6 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
     tr.ray = Ray{0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t out_index = 0;
     uint32_t nbox = 0, ntri = 0;
-    float prim_t = 0.0f;
-    uint32_t prim_idx = 0;
-    V3 col_shadow{0, 0, 0}, col_lit{0, 0, 0};
 
     for (;;) {
         // ---- re-fill idle lanes from the pool (ballot + mbcnt compaction) ----
@@ -687,18 +735,30 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
             if (phase == PH_IDLE && rank < avail) {
                 const uint32_t l = pool_next + rank;
                 if (MODE == MODE_FUSED) {
-                    PixelRef pr = item_pixel(p, pool_item, l);
+                    // batch: item -> (frame, item of that frame); everything here is wave-uniform
+                    uint32_t frame = 0, item_in_frame = pool_item;
+                    const float *f_dir = p.dir, *f_org = p.org;
+                    if (p.n_frames > 1u) {
+                        for (uint32_t k = 1; k < p.n_frames; k++) if (pool_item >= k * p.items_per_frame) frame = k;
+                        item_in_frame = pool_item - frame * p.items_per_frame;
+                        f_dir = p.frames[frame].dir; f_org = p.frames[frame].org;
+                    }
+                    PixelRef pr = item_pixel(p, item_in_frame, l);
                     if (pr.valid) {
                         float dx, dy, dz, ox, oy, oz;
-                        if (p.dir) {
-                            const float *d = p.dir + 3 * (size_t)pr.ray_index, *o = p.org + 3 * (size_t)pr.ray_index;
+                        if (f_dir) {
+                            const float *d = f_dir + 3 * (size_t)pr.ray_index, *o = f_org + 3 * (size_t)pr.ray_index;
                             dx = d[0]; dy = d[1]; dz = d[2]; ox = o[0]; oy = o[1]; oz = o[2];
+                        } else if (p.n_frames > 1u) {
+                            const FrameIO &fr = p.frames[frame];
+                            gen_primary_dir(fr.ipv, fr.near_, fr.far_, p.width, p.height, pr.px, pr.py, dx, dy, dz);
+                            ox = fr.cam[0]; oy = fr.cam[1]; oz = fr.cam[2];
                         } else {
                             gen_primary_dir(p.ipv, p.near_, p.far_, p.width, p.height, pr.px, pr.py, dx, dy, dz);
                             ox = p.cam[0]; oy = p.cam[1]; oz = p.cam[2];
                         }
                         set_ray(tr.ray, ox, oy, oz, dx, dy, dz);
-                        out_index = pr.out_index;
+                        out_index = pr.out_index | (frame << BATCH_FRAME_SHIFT);   // frame is 0 unless this is a batch
                         nbox = 0; ntri = 0;
                         trav_begin<COUNT>(s, tr, T_PRIMARY0, st.sp_init(tid), nbox);
                         phase = PH_PRIMARY | ray_pos_flag(tr.ray);
@@ -799,30 +859,47 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                 *reinterpret_cast<float4 *>(p.hits + 4 * (size_t)out_index) = make_float4(tr.t, tr.u, tr.v, __uint_as_float(tr.idx));
                 if (COUNT && p.counts) { p.counts[2 * (size_t)out_index] = nbox; p.counts[2 * (size_t)out_index + 1] = ntri; }
                 phase = PH_IDLE;
-            } else if (phase & PH_PRIMARY) {
-                prim_t = tr.t; prim_idx = tr.idx;
+            } else {
+              // this lane's output buffers: the kernel arguments, or for a batch its frame's entry of the LDS table
+              float *o_rgba = p.rgba, *o_t = p.hit_t;
+              uint32_t *o_id = p.hit_id, *o_cnt = p.counts;
+              uint32_t out_i = out_index;
+              if (p.n_frames > 1u) {
+                  const uint32_t f = out_index >> BATCH_FRAME_SHIFT;
+                  out_i = out_index & ((1u << BATCH_FRAME_SHIFT) - 1u);
+                  o_rgba = (float *)(uintptr_t)lds_frame_out[f][0]; o_id = (uint32_t *)(uintptr_t)lds_frame_out[f][1];
+                  o_t = (float *)(uintptr_t)lds_frame_out[f][2];    o_cnt = (uint32_t *)(uintptr_t)lds_frame_out[f][3];
+              }
+              if (phase & PH_PRIMARY) {
+                // The primary hit record is final here, and so is the pixel's colour unless the shadow ray finds an
+                // occluder: both are written now, and only the in-shadow colour waits (in LDS) for the shadow
+                // traversal.  Nothing of the pixel but its output index stays in registers across that traversal
+                // (keeping both candidate colours, t and the triangle id live cost the 64-VGPR build 41 spilled
+                // registers: 164 MB of scratch writes per 1080p frame).
+                if (o_t) o_t[out_i] = tr.t;
                 if (tr.t < T_HIT_LIMIT) {
+                    if (o_id) o_id[out_i] = tr.idx;
                     Ray sray;
+                    V3 col_shadow, col_lit;
                     shade_primary<MAT>(s, p, tr, col_shadow, col_lit, sray);
+                    if (o_rgba) store_frag_col(o_rgba, out_i, col_lit.x, col_lit.y, col_lit.z);
+                    lds_shadow_col[tid] = col_shadow.x; lds_shadow_col[BLOCK + tid] = col_shadow.y; lds_shadow_col[2 * BLOCK + tid] = col_shadow.z;
                     tr.ray = sray;
                     trav_begin<COUNT>(s, tr, T_PRIMARY0, st.sp_init(tid), nbox);
                     phase = PH_SHADOW | ray_pos_flag(sray);
                 } else {
                     V3 c = skybox(tr.ray.dx, tr.ray.dy, tr.ray.dz);
-                    if (p.rgba) *reinterpret_cast<float4 *>(p.rgba + 4 * (size_t)out_index) = make_float4(c.x, c.y, c.z, 1.0f);
-                    if (p.hit_id) p.hit_id[out_index] = 0xFFFFFFFFu;
-                    if (p.hit_t) p.hit_t[out_index] = prim_t;
-                    if (COUNT && p.counts) { p.counts[2 * (size_t)out_index] = nbox; p.counts[2 * (size_t)out_index + 1] = ntri; }
+                    if (o_rgba) store_frag_col(o_rgba, out_i, c.x, c.y, c.z);
+                    if (o_id) o_id[out_i] = 0xFFFFFFFFu;
+                    if (COUNT && o_cnt) { o_cnt[2 * (size_t)out_i] = nbox; o_cnt[2 * (size_t)out_i + 1] = ntri; }
                     phase = PH_IDLE;
                 }
-            } else {  // PH_SHADOW finished
-                const bool shadow = tr.t < T_HIT_LIMIT;
-                V3 c = shadow ? col_shadow : col_lit;
-                if (p.rgba) *reinterpret_cast<float4 *>(p.rgba + 4 * (size_t)out_index) = make_float4(c.x, c.y, c.z, 1.0f);
-                if (p.hit_id) p.hit_id[out_index] = prim_idx;
-                if (p.hit_t) p.hit_t[out_index] = prim_t;
-                if (COUNT && p.counts) { p.counts[2 * (size_t)out_index] = nbox; p.counts[2 * (size_t)out_index + 1] = ntri; }
+              } else {  // PH_SHADOW finished: an occluded pixel takes its in-shadow colour (same lane, same address, program order)
+                if (tr.t < T_HIT_LIMIT && o_rgba)
+                    store_frag_col(o_rgba, out_i, lds_shadow_col[tid], lds_shadow_col[BLOCK + tid], lds_shadow_col[2 * BLOCK + tid]);
+                if (COUNT && o_cnt) { o_cnt[2 * (size_t)out_i] = nbox; o_cnt[2 * (size_t)out_i + 1] = ntri; }
                 phase = PH_IDLE;
+              }
             }
         }
     }

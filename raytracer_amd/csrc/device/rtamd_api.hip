@@ -85,6 +85,7 @@ struct rtamd_context {
     uint32_t dyn_incoherent = 32;
     uint32_t leaf_thresh = 8;
     bool shadow_anyhit = true;
+    bool validate_buffers = true;     // *_device entry points check that every buffer lies inside one device allocation (check_range)
     bool launch_timing = true;        // record a start event per launch (rtamd_last_kernel_ms); the stop event is always recorded
     uint32_t queue_stride = 64;
     uint32_t max_blocks_per_cu = 0;   // 0 = as many as fit (8 workgroups = 8 waves per SIMD)
@@ -327,6 +328,24 @@ int static_scratch_ptr(rtamd_context *ctx, uint32_t **out) {
     return RTAMD_OK;
 }
 
+// A *_device entry point gets raw device addresses; a buffer that is shorter than the call needs would be read or
+// written out of bounds by the kernel, and on this hardware a GPU memory fault takes the whole process — possibly the
+// machine's other users — down.  What the host can check it checks: that [ptr, ptr + bytes) lies inside ONE device
+// allocation known to the HIP runtime.  (A sub-allocator such as torch's hands out pieces of larger allocations, so
+// this catches runs past the end of the underlying allocation, the case that faults, not every short buffer.)
+// Addresses the runtime does not know (hipErrorNotFound: e.g. memory mapped by another API) are let through.
+int check_range(rtamd_context *ctx, const void *ptr, uint64_t bytes, const char *what) {
+    if (!ptr || bytes == 0 || !ctx->validate_buffers) return RTAMD_OK;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr) != hipSuccess) { (void)hipGetLastError(); return RTAMD_OK; }
+    const uintptr_t lo = (uintptr_t)base, hi = lo + size, a = (uintptr_t)ptr;
+    if (a < lo || a > hi || bytes > hi - a)
+        return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "%s: %llu bytes at %p run past the end of the device allocation they start in (%zu bytes at %p)",
+                    what, (unsigned long long)bytes, ptr, size, base);
+    return RTAMD_OK;
+}
+
 int check_frame(rtamd_context *ctx, const rtamd_frame_desc *d, const rtamd_frame_out *o) {
     if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
     if (!d || !o) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "frame descriptor / output is NULL");
@@ -356,7 +375,25 @@ void fill_job(const rtamd_context *ctx, const rtamd_frame_desc *d, const rtamd_f
     p.tiles_x = tiles_x;
     p.n_items = local_tiles(n_tiles, d->tile_rank, d->tile_world) * 16u;
     p.rgba = o->rgba32f; p.hit_id = o->hit_id; p.hit_t = o->hit_t; p.counts = o->counts;
+    p.n_frames = 1; p.items_per_frame = p.n_items;
     (void)ctx;
+}
+
+uint64_t frame_out_pixels(const rtamd_frame_desc *d) {
+    const uint32_t n_tiles = n_tiles_of(d->width, d->height, nullptr);
+    return d->tile_world == 1 ? (uint64_t)d->width * d->height : (uint64_t)local_tiles(n_tiles, d->tile_rank, d->tile_world) * RTAMD_TILE_PIXELS;
+}
+
+// Device buffers of one frame: rays for every pixel of the frame, outputs for the pixels this shard owns.
+int check_frame_buffers(rtamd_context *ctx, const rtamd_frame_desc *d, const rtamd_frame_out *o) {
+    const uint64_t n_px = (uint64_t)d->width * d->height, n_out = frame_out_pixels(d);
+    int rc;
+    if ((rc = check_range(ctx, d->dir, n_px * 12, "dir")) || (rc = check_range(ctx, d->org, n_px * 12, "org")) ||
+        (rc = check_range(ctx, o->rgba32f, n_out * 16, "rgba32f")) || (rc = check_range(ctx, o->hit_id, n_out * 4, "hit_id")) ||
+        (rc = check_range(ctx, o->hit_t, n_out * 4, "hit_t")) || (rc = check_range(ctx, o->counts, n_out * 8, "counts")) ||
+        (rc = check_range(ctx, o->rgba8, n_out * 4, "rgba8")))
+        return rc;
+    return RTAMD_OK;
 }
 
 }  // namespace
@@ -478,6 +515,8 @@ int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value) {
     } else if (!std::strcmp(name, "max_blocks_per_cu")) {
         if (value < 0 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "max_blocks_per_cu must be 0..64");
         ctx->max_blocks_per_cu = (uint32_t)value;
+    } else if (!std::strcmp(name, "validate_buffers")) {
+        ctx->validate_buffers = value != 0;
     } else if (!std::strcmp(name, "launch_timing")) {
         ctx->launch_timing = value != 0;
     } else if (!std::strcmp(name, "shadow_anyhit")) {
@@ -753,6 +792,13 @@ int rtamd_dispatch_rays_device(rtamd_context *ctx, const rtamd_dispatch_desc *d,
     DeviceScope dev_scope;
     int rc = dev_scope.enter(ctx);
     if (rc) return rc;
+    {
+        const uint64_t n = (uint64_t)d->width * d->height;
+        if ((rc = check_range(ctx, d->position, n * 12, "position")) || (rc = check_range(ctx, d->normal_mat, n * 16, "normal_mat")) ||
+            (rc = check_range(ctx, o->org, n * 12, "org")) || (rc = check_range(ctx, o->shadow_dir, n * 12, "shadow_dir")) ||
+            (rc = check_range(ctx, o->reflect_dir, n * 12, "reflect_dir")) || (rc = check_range(ctx, o->ambient_dir, n * 12, "ambient_dir")))
+            return rc;
+    }
     DispatchParams p{};
     p.position = d->position; p.normal_mat = d->normal_mat;
     p.noise = (const uint32_t *)ctx->noise.p; p.noise_w = ctx->noise_w; p.noise_h = ctx->noise_h;
@@ -804,6 +850,7 @@ int rtamd_render_device(rtamd_context *ctx, const rtamd_frame_desc *desc, const 
     DeviceScope dev_scope;
     if ((rc = dev_scope.enter(ctx))) return rc;
     if (out->rgba8 && !out->rgba32f) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "rgba8 is made from rgba32f: pass both");
+    if ((rc = check_frame_buffers(ctx, desc, out))) return rc;
     JobParams p;
     fill_job(ctx, desc, out, p);
     if ((rc = launch_main(ctx, MODE_FUSED, out->counts != nullptr, p))) return rc;
@@ -819,6 +866,51 @@ int rtamd_render_device(rtamd_context *ctx, const rtamd_frame_desc *desc, const 
     return RTAMD_OK;
 }
 
+int rtamd_render_batch_device(rtamd_context *ctx, uint32_t n_frames, const rtamd_frame_desc *descs, const rtamd_frame_out *outs) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (n_frames == 0 || n_frames > RTAMD_MAX_BATCH_FRAMES) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "a batch holds 1..%d frames, not %u", RTAMD_MAX_BATCH_FRAMES, n_frames);
+    if (!descs || !outs) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "frame descriptors / outputs are NULL");
+    int rc;
+    bool any_counts = false;
+    for (uint32_t f = 0; f < n_frames; f++) {
+        if ((rc = check_frame(ctx, &descs[f], &outs[f]))) return rc;
+        if (outs[f].rgba8 && !outs[f].rgba32f) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "frame %u: rgba8 is made from rgba32f: pass both", f);
+        const rtamd_frame_desc &a = descs[0], &b = descs[f];
+        if (a.width != b.width || a.height != b.height || a.tile_rank != b.tile_rank || a.tile_world != b.tile_world ||
+            (a.has_tex_coords != 0) != (b.has_tex_coords != 0) || (a.has_normals != 0) != (b.has_normals != 0))
+            return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "frame %u: the frames of a batch share size, tile shard and the has_tex_coords / has_normals flags", f);
+        any_counts = any_counts || outs[f].counts != nullptr;
+    }
+    if (n_frames == 1) return rtamd_render_device(ctx, descs, outs);
+    if (frame_out_pixels(&descs[0]) >= (1ull << BATCH_FRAME_SHIFT) || (uint64_t)descs[0].width * descs[0].height >= (1ull << BATCH_FRAME_SHIFT))
+        return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "frames of a batch are limited to 2^%u - 1 pixels", BATCH_FRAME_SHIFT);
+    if (ctx->variant != 0) {   // the A/B baseline kernel has no batch form: frame by frame
+        for (uint32_t f = 0; f < n_frames; f++) if ((rc = rtamd_render_device(ctx, &descs[f], &outs[f]))) return rc;
+        return RTAMD_OK;
+    }
+    DeviceScope dev_scope;
+    if ((rc = dev_scope.enter(ctx))) return rc;
+    for (uint32_t f = 0; f < n_frames; f++) if ((rc = check_frame_buffers(ctx, &descs[f], &outs[f]))) return rc;
+    JobParams p;
+    fill_job(ctx, &descs[0], &outs[0], p);
+    if (p.n_items == 0) return RTAMD_OK;
+    p.n_frames = n_frames;
+    p.items_per_frame = p.n_items;
+    p.n_items = p.items_per_frame * n_frames;     // <= 8 * 2^28 / 64 items
+    for (uint32_t f = 0; f < n_frames; f++) {
+        FrameIO &io = p.frames[f];
+        io.dir = descs[f].dir; io.org = descs[f].org;
+        io.rgba = outs[f].rgba32f; io.hit_id = outs[f].hit_id; io.hit_t = outs[f].hit_t; io.counts = outs[f].counts;
+        std::memcpy(io.ipv, descs[f].inv_proj_view, sizeof io.ipv);
+        io.near_ = descs[f].near_plane; io.far_ = descs[f].far_plane;
+        std::memcpy(io.cam, descs[f].cam_pos, sizeof io.cam);
+    }
+    if ((rc = launch_main(ctx, MODE_FUSED, any_counts, p))) return rc;
+    for (uint32_t f = 0; f < n_frames; f++)
+        if (outs[f].rgba8 && (rc = rtamd_display_rgba8_device(ctx, outs[f].rgba32f, frame_out_pixels(&descs[f]), outs[f].rgba8))) return rc;
+    return RTAMD_OK;
+}
+
 int rtamd_render_device_static(rtamd_context *ctx, const rtamd_frame_desc *desc, const rtamd_frame_out *out) {
     int rc = check_frame(ctx, desc, out);
     if (rc) return rc;
@@ -828,6 +920,7 @@ int rtamd_render_device_static(rtamd_context *ctx, const rtamd_frame_desc *desc,
                     "(use rtamd_render_device, which allocates its stack columns)", ctx->info.max_depth, STATIC_MAX_DEPTH);
     DeviceScope dev_scope;
     if ((rc = dev_scope.enter(ctx))) return rc;
+    if ((rc = check_frame_buffers(ctx, desc, out))) return rc;
     uint32_t *const ptr = ctx->static_scratch;   // this GPU's copy of `scratch` (hipGetSymbolAddress at context creation)
     JobParams p;
     fill_job(ctx, desc, out, p);
@@ -931,6 +1024,7 @@ int rtamd_trace_device(rtamd_context *ctx, uint64_t n, const float *org, const f
     DeviceScope dev_scope;
     int rc = dev_scope.enter(ctx);
     if (rc) return rc;
+    if ((rc = check_range(ctx, org, n * 12, "org")) || (rc = check_range(ctx, dir, n * 12, "dir")) || (rc = check_range(ctx, hits, n * 16, "hits"))) return rc;
     JobParams p;
     std::memset(&p, 0, sizeof p);
     p.dir = dir; p.org = org; p.hits = hits; p.n_rays = n;
@@ -970,6 +1064,7 @@ int rtamd_generate_rays_offset_device(rtamd_context *ctx, uint32_t width, uint32
     DeviceScope dev_scope;
     int rc = dev_scope.enter(ctx);
     if (rc) return rc;
+    if ((rc = check_range(ctx, dir_out, (uint64_t)width * height * 12, "dir_out"))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->ipv.p, inv_proj_view, 64, hipMemcpyHostToDevice, ctx->stream));
     uint32_t n = width * height;
     hipLaunchKernelGGL(k_generate_rays, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const float *)ctx->ipv.p, near_plane, far_plane, width, height,
@@ -997,6 +1092,8 @@ int rtamd_surface_from_hits_device(rtamd_context *ctx, uint64_t n, const float *
     DeviceScope dev_scope;
     int rc = dev_scope.enter(ctx);
     if (rc) return rc;
+    if ((rc = check_range(ctx, org, n * 12, "org")) || (rc = check_range(ctx, dir, n * 12, "dir")) || (rc = check_range(ctx, hits, n * 16, "hits")) ||
+        (rc = check_range(ctx, position, n * 12, "position")) || (rc = check_range(ctx, normal_mat, n * 16, "normal_mat"))) return rc;
     hipLaunchKernelGGL(k_surface_from_hits, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sdev, n, org, dir, hits,
                        has_normals ? 1u : 0u, position, normal_mat);
     HIP_TRY(ctx, hipGetLastError());
@@ -1063,6 +1160,8 @@ int rtamd_assemble_tile_batch_device(rtamd_context *ctx, const void *gathered, u
     uint32_t n_tiles = n_tiles_of(width, height, &tiles_x);
     uint32_t per_rank = local_tiles(n_tiles, 0, tile_world);
     uint32_t n = width * height;
+    if ((rc = check_range(ctx, gathered, (uint64_t)tile_world * n_frames * per_rank * RTAMD_TILE_PIXELS * elems_per_pixel * 4, "gathered")) ||
+        (rc = check_range(ctx, frames_out, (uint64_t)n_frames * n * elems_per_pixel * 4, "frames_out"))) return rc;
     hipLaunchKernelGGL(k_assemble_tiles, dim3((n + 255) / 256, n_frames), dim3(256), 0, ctx->stream, (const uint32_t *)gathered, width, height,
                        tile_world, tiles_x, per_rank, elems_per_pixel, (uint32_t *)frames_out);
     HIP_TRY(ctx, hipGetLastError());
@@ -1082,6 +1181,7 @@ int rtamd_display_rgba8_device(rtamd_context *ctx, const float *rgba32f, uint64_
     DeviceScope dev_scope;
     int rc = dev_scope.enter(ctx);
     if (rc) return rc;
+    if ((rc = check_range(ctx, rgba32f, n_pixels * 16, "rgba32f")) || (rc = check_range(ctx, rgba8_out, n_pixels * 4, "rgba8_out"))) return rc;
     hipLaunchKernelGGL(k_display_rgba8, dim3((uint32_t)((n_pixels + 255) / 256)), dim3(256), 0, ctx->stream, (const float4 *)rgba32f, n_pixels, rgba8_out);
     HIP_TRY(ctx, hipGetLastError());
     return RTAMD_OK;

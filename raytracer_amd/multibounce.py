@@ -1,0 +1,116 @@
+"""Multi-sample, multi-bounce frames (BASELINE config 5) as a chain of C-ABI calls on device buffers.
+
+The reference's v0 pipeline (src/main.rs:156-203) is one bounce: G-buffer -> ray_dispatcher.frag ->
+three ray_trace.frag passes.  Here the same two shaders' restatements repeat, with
+rtamd_surface_from_hits_device turning a bounce's hit records into the next G-buffer (the reference
+fills it with its rasteriser, src/main.rs:127-140).  Per sample s of a pixel:
+
+    jittered primary  rtamd_generate_rays_offset_device (R2 sequence; sample 0 = the pixel centre)
+    closest hit       rtamd_trace_device                           (ray_trace.frag:131-143)
+    for depth 1..D:
+        surface       rtamd_surface_from_hits_device               (position, normal | material)
+        dispatcher    rtamd_dispatch_rays_device                   (ray_dispatcher.frag:26-41)
+        shadow ray    rtamd_trace_device(org, shadow_dir)          -> shadow_hits
+        continuation  rtamd_trace_device(org, reflect_dir)  for even s   (mirror, :41)
+                      rtamd_trace_device(org, ambient_dir)  for odd s    (normalize(n + noise*2-1), :42)
+                      (not after the last depth)
+
+No colour comes out of this: the reference's consumer of these records (shader.frag:120-124) is a TODO
+stub, so parity is pinned at ray level — every buffer of the chain against the CPU oracle
+(tests/test_gpu_multibounce.py).  There is no compute here: every step is a call into librtamd.so.
+"""
+import numpy as np
+
+R2_G = 0.7548776662466927   # plastic-number constant of the R2 low-discrepancy sequence
+
+
+def sample_offset(s):
+    """Sample position inside the pixel for sample index s (s = 0: the pixel centre the reference rasterises)."""
+    return (0.5 + s * R2_G) % 1.0, (0.5 + s * R2_G * R2_G) % 1.0
+
+
+def noise_offset_scale(s, depth, width, height, noise_size=512):
+    """ray_dispatcher's uniform 5 (src/main.rs:161-166): a per-(sample, depth) texel offset, frame / noise scale."""
+    return ((7 * s + 3 * depth) % noise_size / noise_size, (11 * s + 5 * depth) % noise_size / noise_size,
+            width / noise_size, height / noise_size)
+
+
+STAGES = ("dir", "hits", "position", "normal_mat", "org", "shadow_dir", "reflect_dir", "ambient_dir", "shadow_hits", "cont_hits")
+
+
+class Lane:
+    """One sample in flight: a stream and the buffers of the chain (torch tensors on the tracer's GPU)."""
+
+    def __init__(self, torch, dev, n, cam_pos):
+        self.stream = torch.cuda.Stream(device=dev)
+        f = lambda c: torch.empty((n, c), dtype=torch.float32, device=dev)   # noqa: E731
+        self.dir, self.hits, self.pos, self.nm = f(3), f(4), f(3), f(4)
+        self.org2, self.shadow, self.reflect, self.ambient, self.shadow_hits = f(3), f(3), f(3), f(3), f(4)
+        self.org3, self.dir2 = f(3), f(3)    # the continuation's origin / direction must survive the next dispatch
+        self.cam_org = torch.tensor(cam_pos, dtype=torch.float32, device=dev).repeat(n, 1).contiguous()
+        self.rays = torch.zeros((), dtype=torch.int64, device=dev)
+
+
+class MultiBounce:
+    def __init__(self, tracer, width, height, inv_proj_view, cam_pos, light_pos, has_normals, depth=3, lanes=4, device=0, noise_size=512):
+        import torch
+        self.torch = torch
+        self.tr, self.W, self.H, self.n = tracer, int(width), int(height), int(width) * int(height)
+        self.inv = np.asarray(inv_proj_view, np.float32).reshape(16)
+        self.cam = tuple(float(x) for x in cam_pos)
+        self.light = tuple(float(x) for x in light_pos)
+        self.has_n, self.depth, self.noise_size = int(bool(has_normals)), int(depth), int(noise_size)
+        dev = torch.device("cuda", device)
+        self.lanes = [Lane(torch, dev, self.n, self.cam) for _ in range(max(1, min(8, lanes)))]
+
+    def sample(self, s, lane=None, record=None):
+        """Enqueue sample s on a lane's stream.  record: a dict that receives a device clone of every stage buffer,
+        keyed (depth, stage) with depth 0 = the primary stage (for tests)."""
+        torch, tr, n, W, H = self.torch, self.tr, self.n, self.W, self.H
+        lane = lane if lane is not None else self.lanes[s % len(self.lanes)]
+
+        def rec(depth, **bufs):
+            if record is not None:
+                for k, v in bufs.items():
+                    record[(depth, k)] = v.clone()      # on the lane's stream, behind the call that filled v
+
+        with torch.cuda.stream(lane.stream):
+            tr.set_stream(lane.stream.cuda_stream)
+            ox, oy = sample_offset(s)
+            tr.generate_rays_offset_device(W, H, self.inv, ox, oy, lane.dir.data_ptr())
+            tr.trace_device(n, lane.cam_org.data_ptr(), lane.dir.data_ptr(), lane.hits.data_ptr())
+            lane.rays += n
+            rec(0, dir=lane.dir, hits=lane.hits)
+            org, d = lane.cam_org, lane.dir
+            for depth in range(1, self.depth + 1):
+                tr.surface_from_hits_device(n, org.data_ptr(), d.data_ptr(), lane.hits.data_ptr(), self.has_n, lane.pos.data_ptr(), lane.nm.data_ptr())
+                nos = noise_offset_scale(s, depth, W, H, self.noise_size)
+                tr.dispatch_rays_device(W, H, lane.pos.data_ptr(), lane.nm.data_ptr(), self.light, self.cam, nos, org_ptr=lane.org2.data_ptr(),
+                                        shadow_dir_ptr=lane.shadow.data_ptr(), reflect_dir_ptr=lane.reflect.data_ptr(), ambient_dir_ptr=lane.ambient.data_ptr())
+                surfaces = (lane.nm[:, 3] != 1e30).sum()
+                tr.trace_device(n, lane.org2.data_ptr(), lane.shadow.data_ptr(), lane.shadow_hits.data_ptr())
+                lane.rays += surfaces
+                rec(depth, position=lane.pos, normal_mat=lane.nm, org=lane.org2, shadow_dir=lane.shadow, reflect_dir=lane.reflect,
+                    ambient_dir=lane.ambient, shadow_hits=lane.shadow_hits)
+                if depth < self.depth:
+                    cont = lane.reflect if s % 2 == 0 else lane.ambient
+                    lane.dir2.copy_(cont)
+                    lane.org3.copy_(lane.org2)
+                    tr.trace_device(n, lane.org3.data_ptr(), lane.dir2.data_ptr(), lane.hits.data_ptr())
+                    lane.rays += surfaces
+                    rec(depth, cont_hits=lane.hits)
+                    org, d = lane.org3, lane.dir2
+        return lane
+
+    def synchronize(self):
+        for lane in self.lanes:
+            lane.stream.synchronize()
+
+    def rays_traced(self, reset=False):
+        """Traversals actually started (NO_RAY entries are not counted) since the last reset."""
+        self.synchronize()
+        total = int(sum(int(lane.rays.item()) for lane in self.lanes))
+        if reset:
+            for lane in self.lanes:
+                lane.rays.zero_()
+        return total

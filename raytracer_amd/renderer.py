@@ -184,6 +184,20 @@ class HipRayTracer:
         o = _ffi.FrameOut(rgba_ptr or None, hit_id_ptr or None, hit_t_ptr or None, counts_ptr or None, rgba8_ptr or None)
         self._check(self._lib.rtamd_render_device(self._h, ctypes.byref(d), ctypes.byref(o)))
 
+    def render_batch_device(self, width, height, frames, has_tex_coords=False, has_normals=False, tile_rank=0, tile_world=1):
+        """rtamd_render_batch_device: up to 8 frames in one launch.  frames: a sequence of dicts with the per-frame
+        keyword arguments of render_device (dir_ptr, org_ptr | camera; rgba_ptr, hit_id_ptr, hit_t_ptr, counts_ptr, rgba8_ptr)."""
+        n = len(frames)
+        descs = (_ffi.FrameDesc * n)()
+        outs = (_ffi.FrameOut * n)()
+        for k, fr in enumerate(frames):
+            dp, op = fr.get("dir_ptr", 0), fr.get("org_ptr", 0)
+            descs[k] = self._frame_desc(width, height, ctypes.c_void_p(dp) if dp else None, ctypes.c_void_p(op) if op else None, fr.get("camera"),
+                                        has_tex_coords, has_normals, tile_rank, tile_world)
+            outs[k] = _ffi.FrameOut(fr.get("rgba_ptr") or None, fr.get("hit_id_ptr") or None, fr.get("hit_t_ptr") or None,
+                                    fr.get("counts_ptr") or None, fr.get("rgba8_ptr") or None)
+        self._check(self._lib.rtamd_render_batch_device(self._h, n, descs, outs))
+
     def render_device_static(self, width, height, dir_ptr=0, org_ptr=0, camera=None, has_tex_coords=False, has_normals=False,
                              tile_rank=0, tile_world=1, rgba_ptr=0, hit_id_ptr=0, hit_t_ptr=0, counts_ptr=0, rgba8_ptr=0):
         """rtamd_render_device_static: render_device for callers that cannot allocate (static launch scratch)."""

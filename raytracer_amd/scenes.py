@@ -9,6 +9,8 @@ host layer (Model.from_arrays -> BVHBuilder) like any loaded OBJ.
   subdivide()     midpoint subdivision (C2: bunny x2 -> 80 016 triangles)
   checker_texture() / noise_texture()  RGB8 albedo stand-ins for F16s.bmp / uv_debug.png
 """
+import math
+
 import numpy as np
 
 
@@ -204,3 +206,18 @@ def noise_texture(width=512, height=256, seed=11):
     t = np.kron(base, np.ones((32, 32, 1)))
     t = 0.85 * t + 0.15 * rng.integers(0, 256, (height, width, 3))
     return np.clip(t, 0, 255).astype(np.uint8)
+
+
+def framing_camera(positions, dist, offset=(1.0, 0.4, 0.6), fov_deg=120.0):
+    """The camera the golden fixtures were made with (tests/golden/make_golden.py:camera_for, same arithmetic): the
+    reference's defaults — fovy 120 degrees, up +y (src/rendering/camera.rs:6-7,34-42) — placed `dist` bounding-box
+    radii from the model's centre along `offset`, looking at the centre.  Returns (position f32[3], direction f32[3], fov)."""
+    pos = np.asarray(positions).reshape(-1, 3)
+    lo, hi = pos.min(0), pos.max(0)
+    c = (lo + hi) / 2
+    r = np.linalg.norm(hi - lo) / 2
+    off = np.asarray(offset, np.float64)
+    eye = c + dist * r * off / np.linalg.norm(off)
+    d = c - eye
+    d /= np.linalg.norm(d)
+    return eye.astype(np.float32), d.astype(np.float32), math.radians(fov_deg)

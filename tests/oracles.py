@@ -82,6 +82,8 @@ class OracleA:
         L.oa_trace.restype = ctypes.c_int
         L.oa_raycreate.argtypes = [ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_float, ctypes.c_float, vp]
         L.oa_raycreate.restype = None
+        L.oa_raycreate_offset.argtypes = [ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp]
+        L.oa_raycreate_offset.restype = None
         L.oa_set_flush_denormals.argtypes = [ctypes.c_int]
         L.oa_dispatch.argtypes = [ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp]
         L.oa_dispatch.restype = None
@@ -166,10 +168,10 @@ class OracleA:
         rc = self.L.oa_trace(ctypes.byref(sc), n, o.ctypes.data, d.ctypes.data, hits.ctypes.data, counts.ctypes.data, nthreads)
         return {"hits": hits, "counts": counts, "overflow": rc != 0}
 
-    def raycreate(self, width, height, inv_proj_view, near, far):
+    def raycreate(self, width, height, inv_proj_view, near, far, offset=(0.5, 0.5)):
         m = np.ascontiguousarray(inv_proj_view, dtype=np.float32).reshape(16)
         out = np.zeros((height, width, 3), np.float32)
-        self.L.oa_raycreate(width, height, m.ctypes.data, near, far, out.ctypes.data)
+        self.L.oa_raycreate_offset(width, height, m.ctypes.data, near, far, float(offset[0]), float(offset[1]), out.ctypes.data)
         return out
 
 

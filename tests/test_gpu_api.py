@@ -538,3 +538,151 @@ def test_coherence_feedback_separates_camera_rays_from_soup(tracer, atrium):
     sig = frames(70, camera=(c2.inv_proj_view(), c2.position))
     ts = [t for _, _, t in sig]
     assert sig[0][1] < 0.5 and ts[0] == 1 and all(t == 32 for t in ts[1:65]) and ts[65] == 1 and ts[66] == 32
+
+
+def _batch_vs_single(tracer, w, h, frames_in, has_tc, has_n, tile_rank=0, tile_world=1, with8=False, counts=True):
+    """frames_in: list of dicts (dir/org device tensors, or camera).  Renders every frame alone (rtamd_render_device) and all of
+    them in one launch (rtamd_render_batch_device) and returns the two lists of output dicts."""
+    import torch
+    from raytracer_amd.renderer import TILE_PIXELS
+    n_out = w * h if tile_world == 1 else tracer.local_tile_count(w, h, tile_rank, tile_world) * TILE_PIXELS
+    dev = torch.device("cuda", 0)
+
+    def outputs():
+        o = {"rgba": torch.full((n_out, 4), -3.0, dtype=torch.float32, device=dev), "hit_id": torch.full((n_out,), 77, dtype=torch.int32, device=dev),
+             "hit_t": torch.full((n_out,), -3.0, dtype=torch.float32, device=dev)}
+        if counts:
+            o["counts"] = torch.full((n_out, 2), 77, dtype=torch.int32, device=dev)
+        if with8:
+            o["rgba8"] = torch.full((n_out,), 77, dtype=torch.int32, device=dev)
+        return o
+
+    def args(fin, o):
+        a = {k + "_ptr": v.data_ptr() for k, v in o.items()}
+        if "camera" in fin:
+            a["camera"] = fin["camera"]
+        else:
+            a["dir_ptr"], a["org_ptr"] = fin["dir"].data_ptr(), fin["org"].data_ptr()
+        return a
+
+    for fin in frames_in:      # the library cannot know a device buffer's size: a short ray array would be read out of bounds
+        assert "camera" in fin or (fin["dir"].numel() == 3 * w * h and fin["org"].numel() == 3 * w * h)
+    single, batch = [outputs() for _ in frames_in], [outputs() for _ in frames_in]
+    for fin, o in zip(frames_in, single):
+        tracer.render_device(w, h, has_tex_coords=has_tc, has_normals=has_n, tile_rank=tile_rank, tile_world=tile_world, **args(fin, o))
+    tracer.render_batch_device(w, h, [args(fin, o) for fin, o in zip(frames_in, batch)], has_tex_coords=has_tc, has_normals=has_n,
+                               tile_rank=tile_rank, tile_world=tile_world)
+    tracer.synchronize()
+    return single, batch
+
+
+def test_batch_of_frames_equals_frame_by_frame(tracer):
+    """rtamd_render_batch_device: several frames (different rays, on-device cameras, different origins) through ONE persistent
+    launch give, frame by frame, the bits of rtamd_render_device — hit buffers, colours, test counters, the 8-bit output;
+    also with lane re-fill forced on (lanes of one wave then belong to different frames), on a tile shard, for ragged
+    frames and for a full batch of 8."""
+    import torch
+    g = load_golden("f16")
+    h, w = g["dir"].shape[:2]
+    tracer.upload_scene(g["scene"])
+    tracer.upload_texture(0, g["tex0"]); tracer.upload_texture(1, g["tex1"])
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 3)).to(dev)   # noqa: E731
+    eye, d, fov = scenes.framing_camera(g["positions"], 0.55)
+    cams = [host.Camera(w / h, fov=fov, position=eye, direction=d), host.Camera(w / h, fov=math.radians(70), position=eye * np.float32(1.3), direction=d)]
+    frames = [{"dir": t(g["dir"]), "org": t(g["org"])},
+              {"dir": t(g["dir"][::-1]), "org": t(g["org"])},                                        # upside down
+              {"camera": (cams[0].inv_proj_view(), cams[0].position)},                               # rays made on the device
+              {"dir": t(g["dir"][:, ::-1]), "org": t(g["org"] + np.float32([0.3, -0.2, 0.1]))},      # mirrored, moved eye
+              {"camera": (cams[1].inv_proj_view(), cams[1].position)}]
+
+    def same(single, batch):
+        for k, (a, b) in enumerate(zip(single, batch)):
+            for name in a:
+                assert torch.equal(a[name].view(torch.int32), b[name].view(torch.int32)), (k, name)
+
+    single, batch = _batch_vs_single(tracer, w, h, frames, 1, 1)
+    same(single, batch)
+    ids = [o["hit_id"] for o in batch]
+    assert all(1000 < int((i != -1).sum()) < w * h for i in ids) and not torch.equal(ids[0], ids[1]) and not torch.equal(ids[2], ids[4])
+    assert torch.equal(batch[2]["hit_id"], batch[0]["hit_id"])       # frame 2's camera is the fixture's: same picture from device-made rays
+    try:
+        tracer.set_option("dyn_thresh", 32)                           # re-fill idle lanes mid-item: a wave's lanes span frames
+        same(*_batch_vs_single(tracer, w, h, frames, 1, 1))
+        same(single, _batch_vs_single(tracer, w, h, frames, 1, 1)[1])
+    finally:
+        tracer.set_option("dyn_thresh", 0)
+    same(*_batch_vs_single(tracer, w, h, frames[:3], 1, 1, tile_rank=1, tile_world=3, with8=True))
+    # ragged frames, the full 8 of a batch; frame outputs may be partly absent
+    rw, rh = 37, 19
+    sub = lambda a, k: t(np.ascontiguousarray(a[5 * k:5 * k + rh, 10 * k:10 * k + rw]))   # noqa: E731  (k <= 7: inside the 160x120 fixture)
+    small = [{"dir": sub(g["dir"], k), "org": sub(g["org"], k)} for k in range(8)]
+    same(*_batch_vs_single(tracer, rw, rh, small, 1, 1, counts=False))
+    one = torch.zeros((w * h, 4), dtype=torch.float32, device=dev)
+    tracer.render_batch_device(w, h, [{"dir_ptr": frames[0]["dir"].data_ptr(), "org_ptr": frames[0]["org"].data_ptr(), "rgba_ptr": one.data_ptr()}], 1, 1)
+    tracer.synchronize()
+    assert torch.equal(one, single[0]["rgba"])                        # a batch of one is rtamd_render_device
+    f0 = {"dir_ptr": frames[0]["dir"].data_ptr(), "org_ptr": frames[0]["org"].data_ptr(), "rgba_ptr": one.data_ptr()}
+    with pytest.raises(RtamdError):
+        tracer.render_batch_device(w, h, [f0] * 9, 1, 1)
+    with pytest.raises(RtamdError):
+        tracer.render_batch_device(w, h, [], 1, 1)
+
+
+def test_config1_f16_640x480_matches_oracle(tracer, oracle_a):
+    """BASELINE config 1 as stated: the reference's default scene (src/main.rs:23,30: f16.obj, its two BMP textures) at
+    640x480, bench.py's `f16_640x480` workload.  The 160x120 llvmpipe fixture is this camera at a quarter of the
+    resolution (tests/test_host_layer.py); here the full frame equals oracle A: hit buffers bit for bit, colour far
+    inside the 1/255 bound."""
+    import bench
+    model, camera, w, h, tex = bench.build_workload("f16_640x480")
+    assert (w, h) == (640, 480)
+    sc = model.scene_arrays()
+    tracer.upload_scene(sc)
+    tracer.upload_texture(0, tex[0]); tracer.upload_texture(1, tex[1])
+    dirs, orgs = camera.primary_rays(w, h)
+    for variant in (0, 1):
+        tracer.set_kernel_variant(variant)
+        try:
+            r = tracer.render(w, h, dir=dirs, org=orgs, has_tex_coords=1, has_normals=1)
+            d = tracer.render(w, h, camera=(camera.inv_proj_view(), camera.position), has_tex_coords=1, has_normals=1)   # rays made on the device
+        finally:
+            tracer.set_kernel_variant(0)
+        a = oracle_a.render(sc, dirs, orgs, 1, 1, tex[0], tex[1], nthreads=16)
+        assert np.array_equal(r["hit_id"], a["hit_id"]) and np.array_equal(bits(r["hit_t"]), bits(a["hit_t"]))
+        assert rgb_err_255(r["rgba"], a["rgba"]).max() <= 0.05
+        for k in ("hit_id", "hit_t", "rgba"):
+            assert np.array_equal(bits(r[k]) if k != "hit_id" else r[k], bits(d[k]) if k != "hit_id" else d[k]), k
+    hit = r["hit_id"] != 0xFFFFFFFF
+    assert 0.05 < hit.mean() < 0.9
+    mats = sc["triangles"]["mat_idx"][r["hit_id"][hit]]
+    assert (mats == 0).any() and (mats == 1).any()              # both textures are on screen
+
+
+def test_device_buffers_are_range_checked(tracer):
+    """A "_device" call whose buffer would run past the end of the device allocation it starts in is refused on the host
+    (rtamd_set_option "validate_buffers", default on) instead of faulting on the GPU."""
+    import torch
+    g = load_golden("cube")
+    tracer.upload_scene(g["scene"])
+    dev = torch.device("cuda", 0)
+    w = h = 2048                                           # 48 MiB of rays: an allocation of its own in torch's caching allocator
+    rays = torch.zeros((w * h, 3), dtype=torch.float32, device=dev)
+    rays[:, 2] = -1.0
+    out = torch.zeros((w * (h + 1), 4), dtype=torch.float32, device=dev)
+    tracer.render_device(w, h, rays.data_ptr(), rays.data_ptr(), rgba_ptr=out.data_ptr())           # fits
+    tracer.synchronize()
+    with pytest.raises(RtamdError) as e:                   # one more row of pixels than the ray buffers hold
+        tracer.render_device(w, h + 1, rays.data_ptr(), rays.data_ptr(), rgba_ptr=out.data_ptr())
+    assert e.value.code == -1 and "run past the end" in str(e.value)
+    with pytest.raises(RtamdError):
+        tracer.render_device_static(w, h + 1, rays.data_ptr(), rays.data_ptr(), rgba_ptr=out.data_ptr())
+    with pytest.raises(RtamdError):
+        tracer.render_batch_device(w, h + 1, [{"dir_ptr": rays.data_ptr(), "org_ptr": rays.data_ptr(), "rgba_ptr": out.data_ptr()}] * 2)
+    hits = torch.zeros((w * h, 4), dtype=torch.float32, device=dev)
+    with pytest.raises(RtamdError):
+        tracer.trace_device(w * h + 64, rays.data_ptr(), rays.data_ptr(), hits.data_ptr())
+    with pytest.raises(RtamdError):
+        tracer.trace_device(w * h, rays.data_ptr(), rays.data_ptr(), hits.data_ptr() + 16 * 4096)     # output shifted past its end
+    tracer.trace_device(w * h, rays.data_ptr(), rays.data_ptr(), hits.data_ptr())
+    tracer.synchronize()

@@ -233,6 +233,8 @@ def test_offset_ray_generation(tracer, oracle_a):
     tracer.synchronize()
     c, same, right = (o.cpu().numpy().reshape(H, W, 3) for o in out)
     assert np.array_equal(bits(c), bits(same))
+    from raytracer_amd.host import FAR, NEAR
+    assert np.array_equal(bits(right), bits(oracle_a.raycreate(W, H, inv, NEAR, FAR, offset=(1.0, 0.5))))    # any offset: the oracle's bits
     mid = (c[:, :-1] + c[:, 1:]) / 2
     mid /= np.linalg.norm(mid, axis=-1, keepdims=True)
     assert np.abs(right[:, :-1] - mid).max() < 2e-3

@@ -238,3 +238,19 @@ def test_unorm8_conversion_formula_is_exact_division():
         e = rnd(Fraction(float(x)) - Fraction(float(q)) * 255)
         q2 = rnd(Fraction(float(q)) + Fraction(float(e)) * Fraction(float(r)))
         assert q2 == x / np.float32(255.0), xi
+
+
+def test_config1_workload_is_the_f16_fixture_at_full_size():
+    """bench.py's f16_640x480 (BASELINE config 1) takes scene, textures and camera from the committed llvmpipe fixture:
+    its camera at the fixture's 160x120 gives the fixture's rays bit for bit, so the 640x480 frame is the frame the
+    reference shader was pinned on, at four times the resolution."""
+    import bench
+    from common import bits, load_golden
+    model, camera, w, h, tex = bench.build_workload("f16_640x480")
+    g = load_golden("f16")
+    assert (w, h) == (640, 480) and model.has_tex_coords() and model.has_normals()
+    d, o = camera.primary_rays(160, 120)
+    assert np.array_equal(bits(d), bits(g["dir"])) and np.array_equal(bits(o), bits(g["org"]))
+    sc = model.scene_arrays()
+    assert len(sc["triangles"]) == 4056 and np.array_equal(sc["nodes"], g["nodes"])
+    assert tex[0].shape == (1024, 1024, 3) and tex[1].shape == (512, 256, 3)     # F16s.bmp, F16t.bmp (256 wide, 512 high)

@@ -2,18 +2,19 @@
 # Runs on the GPU box (via gpurun): kernel-trace stats + separate PMC passes for
 # one bench variant; raw output under gpurun_out/prof_<tag>/, summary printed by
 # tools/pmc_summary.py.  Usage: tools/profile_gpu.sh <tag> <bench args...>
+# The PMC passes run 16 steps after 8 of warm-up: with the default 8 frames per launch every profiled dispatch of the
+# dominant kernel holds 8 frames (tools/make_counters.py divides by that).
 set -e -o pipefail
 tag=$1; shift
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-# under rocprofv3 the HIP runtime starts before bench.py can set this (bench.py: frames in flight need their own queues)
-export GPU_MAX_HW_QUEUES=16
+# GPU_MAX_HW_QUEUES stays at the box's value (bench.py's batched launches need no extra hardware queues)
 out=gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --no-cpu-baseline "$@" > "$out/trace.log" 2>&1
 pass() {
   name=$1; shift
-  timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$out/pmc_$name" -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline $BENCH_ARGS > "$out/pmc_$name.log" 2>&1
+  timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$out/pmc_$name" -- python3 bench.py --steps ${PMC_STEPS:-16} --warmup ${PMC_WARMUP:-8} --no-cpu-baseline $BENCH_ARGS > "$out/pmc_$name.log" 2>&1
 }
 BENCH_ARGS="$*"
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE
