@@ -152,6 +152,9 @@ def main():
                          "every rank produces from its RGBA32F share; f32 = the RGBA32F shares themselves: 33 MB per 1080p frame, "
                          "i.e. 138 GB/s at this frame rate — more than an xGMI link carries")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extra measurements after the timed region (one frame at a time, non-overlapping batches): "
+                         "for profiler passes, where every dispatch of the kernel should hold the same number of frames")
     args = ap.parse_args()
 
     import torch
@@ -215,7 +218,8 @@ def main():
         # 134 us per frame with one frame per launch, 52 us with 4, 37 us with 8
         B = args.gather_batch if args.gather_batch > 0 else (args.batch if args.batch > 0 else (8 if n_px <= 1920 * 1080 else 2))
     else:
-        B = args.batch if args.batch > 0 else (2 if scene_mb > 256 else 8)
+        # 8 frames per launch, 4 for short runs (a 20-step run then still has five launches to alternate over the two streams)
+        B = args.batch if args.batch > 0 else (2 if scene_mb > 256 else 8 if args.steps >= 64 else 4)
     B = max(1, min(8, B))
     if args.variant != 0:
         B = 1
@@ -378,7 +382,7 @@ def main():
     overlapped_launch_ms = float(np.mean(full))
     launch_ms = overlapped_launch_ms
     n_alone = 0
-    if S > 1 and world == 1:
+    if S > 1 and world == 1 and not args.no_extras:
         launch_events.clear()
         n_alone = max(5, min(60, args.steps // B))
         torch.cuda.synchronize()
@@ -391,7 +395,7 @@ def main():
 
     # ---- untimed extra for the record: the same frame one at a time (what a caller that waits for every frame sees)
     serial_ms = None
-    if world == 1 and B > 1:
+    if world == 1 and B > 1 and not args.no_extras:
         n_serial = max(10, min(200, args.steps))
         torch.cuda.synchronize()
         s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -470,10 +474,16 @@ def main():
         if tcp:
             roof["l1"] = {"tcp_cache_accesses_per_frame": tcp, "achieved_G_s": round(tcp / frame_s / 1e9, 2), "peak_G_s": TCP_ACCESS_PEAK_G,
                           "frac": round(tcp / frame_s / 1e9 / TCP_ACCESS_PEAK_G, 5)}
+        if "l1_path_busy" in prof:
+            roof.setdefault("l1", {})["path_busy_frac"] = round(prof["l1_path_busy"]["ta_busy_frac"], 4)
+            roof["l1"]["path_busy_note"] = "TA_BUSY_avr / (GRBM_GUI_ACTIVE / 8) of one PMC pass: share of the kernel's cycles in which a CU's texture-address unit (the front of the L1 path) is busy"
         roof["counters_from"] = prof["source"]
         if prof.get("bound") == "tcp_access_rate" and tcp:
             head = {"bound": "l1_access_rate", "achieved": roof["l1"]["achieved_G_s"], "peak": TCP_ACCESS_PEAK_G, "unit": "G cache-line look-ups/s",
-                    "frac": roof["l1"]["frac"]}
+                    "frac": roof["l1"]["frac"],
+                    "frac_note": "TCP_TOTAL_CACHE_ACCESSES per second over one look-up per clock and CU at the 2.4 GHz maximum clock; a 16-byte lane access "
+                                 "counts two look-ups, 8- and 4-byte ones one, and the narrow ones can share a cycle, so a kernel AT the L1's limit reads a few "
+                                 "per cent above 1 (tools/micro/tcp_rate.hip sustains 2.38 look-ups per ns and CU with 16-byte accesses only)"}
         else:
             head = {"bound": "valu_issue", "achieved": round(ginst, 2), "peak": VALU_ISSUE_PEAK_GINST, "unit": "G wave64 VALU instructions/s",
                     "frac": roof["valu"]["issue_frac"]}

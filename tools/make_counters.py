@@ -5,15 +5,17 @@ Usage: tools/make_counters.py <summary.txt> <workload> <frames per launch of the
 import json, os, re, sys
 summary, workload, frames, bound = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 kept = sys.argv[5] if len(sys.argv) > 5 else summary
-vals, cur = {}, None
+vals, cur, busy = {}, None, {}
 for line in open(summary):
     m = re.match(r"\[(pmc_\w+)\] (.*)", line)
     if m:
-        cur = m.group(2) if "k_persistent<0, false" in m.group(2) else None    # the dominant kernel: fused, no test counters
+        cur = m.group(1) if "k_persistent<0, false" in m.group(2) else None    # the dominant kernel: fused, no test counters
         continue
     m = re.match(r"\s+(\w+)\s+([\d.]+)\s+\(n=(\d+)\)", line)
     if m and cur:
         vals[m.group(1)] = (float(m.group(2)), int(m.group(3)))
+        if cur == "pmc_busy":
+            busy[m.group(1)] = float(m.group(2))      # GRBM_GUI_ACTIVE of the SAME pass as TA_BUSY
 need = ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "TCP_TOTAL_CACHE_ACCESSES_sum")
 missing = [k for k in need if k not in vals]
 if missing:
@@ -31,6 +33,12 @@ rec = {"workload": workload, "kernel": "k_persistent<fused>", "bound": bound,
                      **({"l2_hit_rate": vals["TCC_HIT_sum"][0] / (vals["TCC_HIT_sum"][0] + vals["TCC_MISS_sum"][0])} if "TCC_HIT_sum" in vals else {})},
        "note": "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies the 128-B requests of wide (16 B/lane) loads at 64 B, so the read side is "
                "doubled; WRITE_SIZE is exact"}
+if "TA_BUSY_avr" in busy and busy.get("GRBM_GUI_ACTIVE"):
+    # TA_BUSY counts, per CU, the cycles its texture-address unit (the front of the L1 path) is busy; GRBM_GUI_ACTIVE is summed over
+    # the 8 XCDs.  Both are from one pass, so their quotient is the busy share of that dispatch's cycles.
+    rec["l1_path_busy"] = {"ta_busy_avr_cycles": busy["TA_BUSY_avr"], "ta_busy_max_cycles": busy.get("TA_BUSY_max"),
+                           "gui_active_cycles_per_xcd": busy["GRBM_GUI_ACTIVE"] / 8.0,
+                           "ta_busy_frac": busy["TA_BUSY_avr"] / (busy["GRBM_GUI_ACTIVE"] / 8.0)}
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"counters_{workload}.json")
 json.dump(rec, open(out, "w"), indent=1)
 print(out, json.dumps(rec["per_frame"]))

@@ -4,7 +4,7 @@
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-.}"
 tag=${1:-r02}
-tools/profile_gpu.sh ${tag}_atrium --streams 1 > gpurun_out/${tag}_atrium_profile.log 2>&1 || { echo "atrium profile failed"; tail -5 gpurun_out/${tag}_atrium_profile.log; exit 1; }
+tools/profile_gpu.sh ${tag}_atrium --streams 1 --batch 8 > gpurun_out/${tag}_atrium_profile.log 2>&1 || { echo "atrium profile failed"; tail -5 gpurun_out/${tag}_atrium_profile.log; exit 1; }
 cp gpurun_out/prof_${tag}_atrium/summary.txt gpurun_out/${tag}_atrium_summary.txt
 python3 tools/make_counters.py gpurun_out/${tag}_atrium_summary.txt atrium_1080p 8 valu_issue profiles/${tag}_atrium_summary.txt || exit 1
 cp profiles/counters_atrium_1080p.json gpurun_out/
