@@ -79,7 +79,8 @@ const char *rtamd_last_error(const rtamd_context *ctx);
  * Frames in flight: launches on one stream run in stream order; launches issued on
  * DIFFERENT streams may overlap on the GPU, and are meant to: the tail of one frame (its
  * last, slowest work items) then runs beside the start of the next, which on MI355X raises
- * the frame rate of the fused shader by about 1.4x.  The context keeps
+ * the frame rate of the fused shader by about 1.4x (rtamd_render_batch_device
+ * gets the same from ONE launch on one stream, and is the better tool).  The context keeps
  * separate launch scratch (queue counters, stack-spill area, timing events) per stream for
  * up to 8 streams, so a caller pipelines frames by alternating two streams of its own:
  *     set_stream(s[k % 2]); rtamd_render_device(..., out[k % 2]);
