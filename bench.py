@@ -140,13 +140,13 @@ def main():
     ap.add_argument("--workload", default="atrium_1080p")
     ap.add_argument("--variant", type=int, default=0, help="0 persistent (default), 1 static A/B baseline (always one frame per launch)")
     ap.add_argument("--batch", type=int, default=0,
-                    help="frames per launch (rtamd_render_batch_device), 1..8; 1 = one frame at a time.  0 = auto: 8 on one GPU "
+                    help="frames per launch (rtamd_render_batch_device), 1..16; 1 = one frame at a time.  0 = auto: 8 on one GPU "
                          "(2 when the scene records exceed the 256 MB Infinity Cache); with N > 1 the frames of one gather")
     ap.add_argument("--streams", type=int, default=0,
                     help="one GPU: batches alternate over that many streams (0 = auto: 2, so that the tail of one batch runs beside the "
                          "start of the next; 1: launches never overlap)")
     ap.add_argument("--gather-batch", type=int, default=0,
-                    help="N > 1: frames per RCCL gather = frames per launch (0 = auto: 8 up to 1080p, 2 above)")
+                    help="N > 1: frames per RCCL gather = frames per launch (0 = auto up to 1080p: 8 for 2-4 ranks, 16 beyond; 2 for larger frames)")
     ap.add_argument("--gather-format", choices=("f32", "rgba8"), default="rgba8",
                     help="N > 1: what crosses xGMI. rgba8 (default) = the display pass's 8-bit back buffer (util/display.frag) that "
                          "every rank produces from its RGBA32F share; f32 = the RGBA32F shares themselves: 33 MB per 1080p frame, "
@@ -216,18 +216,20 @@ def main():
     if world > 1:
         # measured on one GPU (tools/share_cost.py: a rank's 1/8 share of this frame, render + display pass, two alternating streams):
         # 134 us per frame with one frame per launch, 52 us with 4, 37 us with 8
-        B = args.gather_batch if args.gather_batch > 0 else (args.batch if args.batch > 0 else (8 if n_px <= 1920 * 1080 else 2))
+        # (16 per launch: 33 us).  Auto: a launch of about two whole frames' work — 8 frames up to 4 ranks, 16 beyond
+        B = args.gather_batch if args.gather_batch > 0 else (args.batch if args.batch > 0 else ((8 if world <= 4 else 16) if n_px <= 1920 * 1080 else 2))
     else:
         # 8 frames per launch, 4 for short runs (a 20-step run then still has five launches to alternate over the two streams)
         B = args.batch if args.batch > 0 else (2 if scene_mb > 256 else 8 if args.steps >= 64 else 4)
-    B = max(1, min(8, B))
+    B = max(1, min(16, B))
     if args.variant != 0:
         B = 1
     # Batch j = frames jB .. jB+B-1 renders with one launch on render_streams[j % S] into batch buffer j % S ([B][n_local_out]
     # pixels).  N > 1: `stream` then waits for that stream, converts (rgba8), gathers the buffer, assembles the B scan-line
     # frames and marks the buffer free, while the next batch renders on the other stream.
     S = (max(1, min(4, args.streams)) if args.streams > 0 else (2 if args.variant == 0 else 1)) if world == 1 else 2
-    render_streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
+    # N > 1: two render streams of their own, so that `stream` (gather + assembly) never sits between two renders
+    render_streams = ([stream] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]) if world == 1 else [torch.cuda.Stream(device=dev) for _ in range(S)]
     rgba = [torch.zeros((B * n_local_out, 4), dtype=torch.float32, device=dev) for _ in range(S)]
     consumed = [torch.cuda.Event() for _ in range(S)]   # batch buffer f has been gathered
     d_rgba = rgba[0]

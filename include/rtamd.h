@@ -213,7 +213,7 @@ int rtamd_render_device(rtamd_context *ctx, const rtamd_frame_desc *desc, const 
  * pointer are per frame (outputs may be NULL per frame; rgba8 per frame as in rtamd_render_device).  Limits: 1..
  * RTAMD_MAX_BATCH_FRAMES frames, fewer than 2^28 pixels per frame when n_frames > 1.  Device pointers; enqueues on the
  * context's stream and returns.  No counterpart in the reference. */
-#define RTAMD_MAX_BATCH_FRAMES 8
+#define RTAMD_MAX_BATCH_FRAMES 16
 int rtamd_render_batch_device(rtamd_context *ctx, uint32_t n_frames, const rtamd_frame_desc *descs, const rtamd_frame_out *outs);
 
 /* rtamd_render_device for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses

@@ -82,7 +82,7 @@ struct SceneDev {
 };
 
 // One frame of a batch (rtamd_render_batch_device): its rays or camera in, its pixels out.
-constexpr int MAX_BATCH_FRAMES = 8;           // RTAMD_MAX_BATCH_FRAMES
+constexpr int MAX_BATCH_FRAMES = 16;          // RTAMD_MAX_BATCH_FRAMES
 constexpr uint32_t BATCH_FRAME_SHIFT = 28;    // a lane's out_index carries its frame in the top bits: pixels per frame < 2^28
 struct FrameIO {
     const float *dir, *org;       // nullptr dir => generate from the camera below
@@ -96,6 +96,7 @@ struct FrameIO {
     uint32_t pad;
 };
 static_assert(sizeof(FrameIO) == 136, "FrameIO layout");
+static_assert(MAX_BATCH_FRAMES <= (1 << (32 - BATCH_FRAME_SHIFT)), "the frame index must fit above BATCH_FRAME_SHIFT");
 
 struct JobParams {
     // fused render

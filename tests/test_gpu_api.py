@@ -580,7 +580,7 @@ def test_batch_of_frames_equals_frame_by_frame(tracer):
     """rtamd_render_batch_device: several frames (different rays, on-device cameras, different origins) through ONE persistent
     launch give, frame by frame, the bits of rtamd_render_device — hit buffers, colours, test counters, the 8-bit output;
     also with lane re-fill forced on (lanes of one wave then belong to different frames), on a tile shard, for ragged
-    frames and for a full batch of 8."""
+    frames and for a full batch of 16."""
     import torch
     g = load_golden("f16")
     h, w = g["dir"].shape[:2]
@@ -613,10 +613,10 @@ def test_batch_of_frames_equals_frame_by_frame(tracer):
     finally:
         tracer.set_option("dyn_thresh", 0)
     same(*_batch_vs_single(tracer, w, h, frames[:3], 1, 1, tile_rank=1, tile_world=3, with8=True))
-    # ragged frames, the full 8 of a batch; frame outputs may be partly absent
+    # ragged frames, the full 16 of a batch; frame outputs may be partly absent
     rw, rh = 37, 19
-    sub = lambda a, k: t(np.ascontiguousarray(a[5 * k:5 * k + rh, 10 * k:10 * k + rw]))   # noqa: E731  (k <= 7: inside the 160x120 fixture)
-    small = [{"dir": sub(g["dir"], k), "org": sub(g["org"], k)} for k in range(8)]
+    sub = lambda a, k: t(np.ascontiguousarray(a[5 * k:5 * k + rh, 8 * k:8 * k + rw]))   # noqa: E731  (k <= 15: inside the 160x120 fixture)
+    small = [{"dir": sub(g["dir"], k), "org": sub(g["org"], k)} for k in range(16)]
     same(*_batch_vs_single(tracer, rw, rh, small, 1, 1, counts=False))
     one = torch.zeros((w * h, 4), dtype=torch.float32, device=dev)
     tracer.render_batch_device(w, h, [{"dir_ptr": frames[0]["dir"].data_ptr(), "org_ptr": frames[0]["org"].data_ptr(), "rgba_ptr": one.data_ptr()}], 1, 1)
@@ -624,7 +624,7 @@ def test_batch_of_frames_equals_frame_by_frame(tracer):
     assert torch.equal(one, single[0]["rgba"])                        # a batch of one is rtamd_render_device
     f0 = {"dir_ptr": frames[0]["dir"].data_ptr(), "org_ptr": frames[0]["org"].data_ptr(), "rgba_ptr": one.data_ptr()}
     with pytest.raises(RtamdError):
-        tracer.render_batch_device(w, h, [f0] * 9, 1, 1)
+        tracer.render_batch_device(w, h, [f0] * 17, 1, 1)
     with pytest.raises(RtamdError):
         tracer.render_batch_device(w, h, [], 1, 1)
 
