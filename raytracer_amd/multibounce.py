@@ -45,8 +45,10 @@ class Lane:
         self.stream = torch.cuda.Stream(device=dev)
         f = lambda c: torch.empty((n, c), dtype=torch.float32, device=dev)   # noqa: E731
         self.dir, self.hits, self.pos, self.nm = f(3), f(4), f(3), f(4)
-        self.org2, self.shadow, self.reflect, self.ambient, self.shadow_hits = f(3), f(3), f(3), f(3), f(4)
-        self.org3, self.dir2 = f(3), f(3)    # the continuation's origin / direction must survive the next dispatch
+        # two sets of dispatcher targets, used alternately: a bounce's continuation rays (its origin and its reflect / ambient
+        # directions) must survive the next bounce's dispatcher pass
+        self.targets = [{"org": f(3), "shadow": f(3), "reflect": f(3), "ambient": f(3)} for _ in range(2)]
+        self.shadow_hits = f(4)
         self.cam_org = torch.tensor(cam_pos, dtype=torch.float32, device=dev).repeat(n, 1).contiguous()
         self.rays = torch.zeros((), dtype=torch.int64, device=dev)
 
@@ -85,21 +87,21 @@ class MultiBounce:
             for depth in range(1, self.depth + 1):
                 tr.surface_from_hits_device(n, org.data_ptr(), d.data_ptr(), lane.hits.data_ptr(), self.has_n, lane.pos.data_ptr(), lane.nm.data_ptr())
                 nos = noise_offset_scale(s, depth, W, H, self.noise_size)
-                tr.dispatch_rays_device(W, H, lane.pos.data_ptr(), lane.nm.data_ptr(), self.light, self.cam, nos, org_ptr=lane.org2.data_ptr(),
-                                        shadow_dir_ptr=lane.shadow.data_ptr(), reflect_dir_ptr=lane.reflect.data_ptr(), ambient_dir_ptr=lane.ambient.data_ptr())
+                t = lane.targets[depth & 1]
+                tr.dispatch_rays_device(W, H, lane.pos.data_ptr(), lane.nm.data_ptr(), self.light, self.cam, nos, org_ptr=t["org"].data_ptr(),
+                                        shadow_dir_ptr=t["shadow"].data_ptr(), reflect_dir_ptr=t["reflect"].data_ptr(), ambient_dir_ptr=t["ambient"].data_ptr())
                 surfaces = (lane.nm[:, 3] != 1e30).sum()
-                tr.trace_device(n, lane.org2.data_ptr(), lane.shadow.data_ptr(), lane.shadow_hits.data_ptr())
+                tr.trace_device(n, t["org"].data_ptr(), t["shadow"].data_ptr(), lane.shadow_hits.data_ptr())
                 lane.rays += surfaces
-                rec(depth, position=lane.pos, normal_mat=lane.nm, org=lane.org2, shadow_dir=lane.shadow, reflect_dir=lane.reflect,
-                    ambient_dir=lane.ambient, shadow_hits=lane.shadow_hits)
+                rec(depth, position=lane.pos, normal_mat=lane.nm, org=t["org"], shadow_dir=t["shadow"], reflect_dir=t["reflect"],
+                    ambient_dir=t["ambient"], shadow_hits=lane.shadow_hits)
                 if depth < self.depth:
-                    cont = lane.reflect if s % 2 == 0 else lane.ambient
-                    lane.dir2.copy_(cont)
-                    lane.org3.copy_(lane.org2)
-                    tr.trace_device(n, lane.org3.data_ptr(), lane.dir2.data_ptr(), lane.hits.data_ptr())
+                    cont = t["reflect"] if s % 2 == 0 else t["ambient"]
+                    # hits is read by nothing else from here on: the continuation's records replace the previous bounce's
+                    tr.trace_device(n, t["org"].data_ptr(), cont.data_ptr(), lane.hits.data_ptr())
                     lane.rays += surfaces
                     rec(depth, cont_hits=lane.hits)
-                    org, d = lane.org3, lane.dir2
+                    org, d = t["org"], cont
         return lane
 
     def synchronize(self):

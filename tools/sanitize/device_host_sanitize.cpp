@@ -95,6 +95,25 @@ int main() {
             CHECK(rtamd_set_option(ctx, opt, v) == RTAMD_OK);
             for (int k = 0; k < 12; k++) { CHECK(rtamd_context_set_stream(ctx, st[k % 10]) == RTAMD_OK); rtamd_frame_out o{d_rgba + (k % 10) * n * 4, nullptr, nullptr, nullptr}; CHECK(rtamd_render_device(ctx, &d, &o) == RTAMD_OK); }
         }
+    // round 2: several frames per launch, the entry point that allocates nothing, buffer range checks
+    {
+        CHECK(rtamd_set_option(ctx, "max_blocks_per_cu", 0) == RTAMD_OK); CHECK(rtamd_set_option(ctx, "dyn_thresh", 0) == RTAMD_OK);
+        rtamd_frame_desc ds[17]; rtamd_frame_out os[17];
+        for (int k = 0; k < 17; k++) { ds[k] = d; ds[k].cam_pos[0] = 0.1f * k; os[k] = rtamd_frame_out{d_rgba + (k % 10) * n * 4, nullptr, nullptr, nullptr, nullptr}; }
+        for (uint32_t nf : {1u, 2u, 10u}) CHECK(rtamd_render_batch_device(ctx, nf, ds, os) == RTAMD_OK);
+        CHECK(rtamd_render_batch_device(ctx, 17, ds, os) == RTAMD_ERR_INVALID_ARGUMENT);
+        CHECK(rtamd_render_batch_device(ctx, 0, ds, os) == RTAMD_ERR_INVALID_ARGUMENT);
+        ds[1].width = 2 * W; CHECK(rtamd_render_batch_device(ctx, 2, ds, os) == RTAMD_ERR_INVALID_ARGUMENT); ds[1].width = W;
+        CHECK(rtamd_render_device_static(ctx, &d, &os[0]) == RTAMD_OK);
+        // a buffer that would run past the allocation it starts in is refused on the host: d_rgba holds 10 frames
+        rtamd_frame_out past{d_rgba + 9 * n * 4 + 4, nullptr, nullptr, nullptr, nullptr};
+        CHECK(rtamd_render_device(ctx, &d, &past) == RTAMD_ERR_INVALID_ARGUMENT);
+        CHECK(rtamd_render_device_static(ctx, &d, &past) == RTAMD_ERR_INVALID_ARGUMENT);
+        uint32_t *d8 = nullptr; CHECK(hipMalloc(&d8, n * 4) == hipSuccess);
+        CHECK(rtamd_display_rgba8_device(ctx, d_rgba, n, d8) == RTAMD_OK);
+        CHECK(rtamd_display_rgba8_device(ctx, d_rgba, n + 1, d8) == RTAMD_ERR_INVALID_ARGUMENT);
+        CHECK(hipDeviceSynchronize() == hipSuccess); (void)hipFree(d8);
+    }
     CHECK(rtamd_abi_version() == RTAMD_ABI_VERSION);
     CHECK(rtamd_set_option(ctx, "no_such", 1) != RTAMD_OK);
     CHECK(hipDeviceSynchronize() == hipSuccess);
