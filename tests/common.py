@@ -4,7 +4,9 @@ import os
 import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-GOLDEN_SCENES = ("cube", "f16", "teapot", "bunny")
+# every model under the reference's res/models: the first four from round 1, the other four from round 2
+# (make_golden.py: FIRST_CASES / MORE_CASES; "testobj" = testObj.obj, five materials, F16t.bmp in both sampler slots)
+GOLDEN_SCENES = ("cube", "f16", "teapot", "bunny", "armadillo", "dome", "sphere", "testobj")
 
 
 def load_golden(name):

@@ -23,7 +23,7 @@ inputs + outputs as compressed .npz files:
   golden_raycreate.npz: ray_trace/ray_create.frag for three cameras (inputs + RGB32F direction target)
   golden_soup.npz: the same as golden_atrium for a 100 000-triangle seeded soup (camera frame + 8192 random rays)
 
-The fixtures are data only.  Usage:  python tests/golden/make_golden.py [--only-atrium | --only-soup | --only-raycreate | --add-uniform]
+The fixtures are data only.  Usage:  python tests/golden/make_golden.py [--only-atrium | --only-soup | --only-raycreate | --only-more-models | --add-uniform]
 """
 import math
 import os
@@ -110,21 +110,40 @@ def add_uniform_to_existing():
     print(f"atrium: b_fused_uniform differs from b_fused (> 1/255) on {int(diff.sum())} of {diff.size} pixels")
 
 
-def main():
+FIRST_CASES = [
+    # name, obj, camera distance (in bbox radii), textures
+    ("cube", "cube.obj", 1.6, None),
+    ("f16", "f16.obj", 0.55, ("F16s.bmp", "F16t.bmp")),
+    ("teapot", "teapot.obj", 0.8, None),
+    ("bunny", "bunny.obj", 0.7, None),
+]
+# the rest of res/models (round 2).  testObj.obj has texture coordinates and FIVE materials; the fused shader declares
+# modelTextures[2] (:21), so an index above 1 is out of the array's bounds and its colour undefined — except when every slot
+# holds the same image: F16t.bmp is bound to both, and the fixture pins the colour for that binding only.  (uv_debug.png and
+# F16s.bmp were tried first: the backdrop minifies them to noise, llvmpipe filters RGBA8 texels with 8-bit weights, and
+# between full-contrast neighbours that quantisation alone reaches 1.2/255 on 1-6 pixels of the frame — the fixture would
+# test the rasteriser's filter precision, not the shader.  With F16t.bmp the largest difference is 0.89/255, as on f16.)
+MORE_CASES = [
+    ("armadillo", "armadillo_lowres.obj", 0.6, None),
+    ("dome", "dome.obj", 0.8, None),
+    ("sphere", "sphere.obj", 0.62, None),
+    # camera aimed at the small objects at the origin (materials 1, 2, 4) in front of the backdrop (0) under the light panel (3)
+    ("testobj", "testObj.obj", 0.6, ("F16t.bmp", "F16t.bmp"), (1, 2, 4), (-0.7, 0.5, 1.0)),
+]
+
+
+def main(cases=FIRST_CASES, with_extras=True):
     B = OracleB()
     print("oracle B:", B.renderer)
-    cases = [
-        # name, obj, camera distance (in bbox radii), textures
-        ("cube", "cube.obj", 1.6, None),
-        ("f16", "f16.obj", 0.55, ("F16s.bmp", "F16t.bmp")),
-        ("teapot", "teapot.obj", 0.8, None),
-        ("bunny", "bunny.obj", 0.7, None),
-    ]
-    for name, obj, dist, texs in cases:
+    for name, obj, dist, texs, *focus in cases:
         model = host.ResourceParser.parse_model(open(os.path.join(REF, "models", obj)).read())
         model.build_bvh()
         sc = model.scene_arrays()
-        cam = camera_for(sc["positions"], dist)
+        aim = sc["positions"]
+        if focus:     # frame only the triangles of these materials
+            t = sc["triangles"][np.isin(sc["triangles"]["mat_idx"], focus[0])]
+            aim = sc["positions"][np.unique(np.concatenate([t["p0"], t["p1"], t["p2"]]))]
+        cam = camera_for(aim, dist, *focus[1:2])
         dirs, orgs = cam.primary_rays(W, H)
         tex0 = tex1 = None
         if texs:
@@ -153,6 +172,8 @@ def main():
         print(f"{name}: {len(sc['triangles'])} tris, {len(sc['nodes'])} nodes, {hits}/{W * H} hit pixels, "
               f"{int((b_rand[..., 0] < 1e30).sum())}/4096 random hits -> {os.path.getsize(path) / 1e6:.2f} MB")
 
+    if not with_extras:
+        return
     # secondary-ray dispatcher on a G-buffer derived from the bunny frame just written
     g = dict(np.load(os.path.join(HERE, "golden_bunny.npz")))
     tr = g["b_trace"]
@@ -281,6 +302,8 @@ def raycreate():
 if __name__ == "__main__":
     if "--add-uniform" in sys.argv:
         add_uniform_to_existing()
+    elif "--only-more-models" in sys.argv:
+        main(MORE_CASES, with_extras=False)
     elif "--only-raycreate" in sys.argv:
         raycreate()
     elif "--only-atrium" in sys.argv:

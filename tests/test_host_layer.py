@@ -6,7 +6,7 @@ import math
 import numpy as np
 import pytest
 
-from common import load_golden
+from common import GOLDEN_SCENES, load_golden
 from raytracer_amd import host, scenes
 
 CUBE_OBJ = "\n".join(
@@ -83,7 +83,7 @@ def test_bvh_bit_identical_to_numpy_restatement(kind):
     del rng
 
 
-@pytest.mark.parametrize("name", ["f16", "teapot", "bunny"])
+@pytest.mark.parametrize("name", GOLDEN_SCENES)
 def test_golden_scene_trees_satisfy_invariants(name):
     g = load_golden(name)
     check_invariants(g["nodes"], g["triangles"], g["positions"])
