@@ -132,6 +132,25 @@ def build_workload(name):
     return model, camera, w, h, tex
 
 
+def gather_to_root(send, gathered, rank, world, through_host=False):
+    """The one collective of the N > 1 path: every rank's share `send` ([n] or [n, 4], on the GPU) lands in row `rank` of
+    rank 0's `gathered` ([world, n(, 4)]), enqueued on torch's current stream (RCCL; xGMI between peers).  The rows of
+    `gathered` are handed over as views, so the shares arrive in place and the assembly kernel reads them where they landed.
+    through_host: the one-GPU rehearsal (gloo, all ranks on cuda:0) moves the shares through host memory instead."""
+    import torch
+    import torch.distributed as dist
+    if through_host:
+        mine = send.cpu()
+        parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, gather_list=parts, dst=0)
+        if rank == 0:
+            gathered.copy_(torch.stack(parts))
+    elif rank == 0:
+        dist.gather(send, gather_list=list(gathered.unbind(0)), dst=0)
+    else:
+        dist.gather(send, dst=0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -291,15 +310,7 @@ def main():
             stream.wait_stream(rs)
         if rehearse:
             stream.synchronize()
-            mine = send[f].cpu()
-            parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-            dist.gather(mine, gather_list=parts, dst=0)
-            if rank == 0:
-                gathered.copy_(torch.stack(parts))
-        elif rank == 0:
-            dist.gather(send[f], gather_list=list(gathered.unbind(0)), dst=0)
-        else:
-            dist.gather(send[f], dst=0)
+        gather_to_root(send[f], gathered if rank == 0 else None, rank, world, rehearse)
         if rank == 0:
             tracer.set_stream(stream.cuda_stream)
             tracer.assemble_tile_batch_device(gathered.data_ptr(), W, H, world, 1 if as8 else 4, B, frames_out.data_ptr())

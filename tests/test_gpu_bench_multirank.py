@@ -41,3 +41,48 @@ def test_two_rank_rehearsal_assembles_the_single_gpu_frame(fmt, steps, gather_ba
     assert out["value"] > 0 and out["steps"] == steps and out["scaling"] == "strong"
     # rays are counted over both ranks' shares: the whole frame's primaries
     assert cfg["primary_rays"] == 480 * 270
+
+
+_RCCL_CHILD = r'''
+import sys
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import bench
+
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=dev)          # as bench.py does for N > 1
+stream = torch.cuda.Stream(device=dev)
+torch.cuda.set_stream(stream)
+g = torch.Generator(device="cpu").manual_seed(5)
+for shape, dtype in (((40960,), torch.int32), ((40960, 4), torch.float32)):   # the rgba8 and the f32 gather formats
+    send = (torch.randint(-2**31, 2**31 - 1, shape, generator=g, dtype=torch.int64).to(torch.int32) if dtype == torch.int32
+            else torch.rand(shape, generator=g, dtype=torch.float32)).to(dev)
+    gathered = torch.zeros((1,) + shape, dtype=dtype, device=dev)
+    stream.wait_stream(torch.cuda.default_stream(dev))
+    for _ in range(3):
+        bench.gather_to_root(send, gathered, 0, 1)
+    stream.synchronize()
+    assert torch.equal(gathered[0].view(torch.int32), send.view(torch.int32)), dtype
+stats = torch.tensor([1, 2, 3, 4], dtype=torch.int64, device=dev)
+dist.all_reduce(stats)
+tt = torch.tensor([1.5, 2.5], dtype=torch.float64, device=dev)
+dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+assert stats.tolist() == [1, 2, 3, 4] and tt.tolist() == [1.5, 2.5]
+dist.destroy_process_group()
+print("RCCL_OK", torch.cuda.nccl.version())
+'''
+
+
+@pytest.mark.timeout(300)
+def test_rccl_calls_of_the_multi_gpu_path_on_one_rank():
+    """The collective calls bench.py makes with N > 1 — init_process_group("nccl", device_id=...), its gather_to_root()
+    into row views of the root's buffer on a non-default stream, all_reduce (sum of int64, max of float64), barrier,
+    destroy — through RCCL itself with a world of ONE rank: all a one-GPU box can show of the real backend (the two-rank
+    rehearsal above runs the batching logic over gloo).  A fresh process, so that no process group outlives the test."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, "-c", _RCCL_CHILD, REPO], cwd=REPO, env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0 and "RCCL_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
