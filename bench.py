@@ -222,6 +222,7 @@ def main():
     inv = camera.inv_proj_view()
     d_dir = torch.empty((n_px, 3), dtype=torch.float32, device=dev)
     tracer.generate_rays_device(W, H, inv, d_dir.data_ptr())
+    tracer.synchronize()
     d_org = torch.tensor(np.asarray(camera.position, np.float32), device=dev).repeat(n_px, 1).contiguous()
 
     per_rank_tiles = tracer.tiles_per_rank(W, H, world)

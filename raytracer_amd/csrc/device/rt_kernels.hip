@@ -996,16 +996,14 @@ __global__ void __launch_bounds__(BLOCK) k_static(const SceneDev s, const JobPar
 // ---------------------------------------------------------------------------
 // small utility kernels
 // ---------------------------------------------------------------------------
-__global__ void k_generate_rays(const float *__restrict__ ipv16, float near_, float far_, uint32_t width, uint32_t height, float off_x, float off_y,
+struct Mat4Arg { float m[16]; };   // inverse(proj * view), column-major, by value in the kernel arguments (scalar loads, no staging buffer)
+__global__ void k_generate_rays(const Mat4Arg ipv, float near_, float far_, uint32_t width, uint32_t height, float off_x, float off_y,
                                 float *__restrict__ dir_out) {
-    __shared__ float m[16];
-    if (threadIdx.x < 16) m[threadIdx.x] = ipv16[threadIdx.x];
-    __syncthreads();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= width * height) return;
     uint32_t px = i % width, py = i / width;
     float dx, dy, dz;
-    gen_primary_dir(m, near_, far_, width, height, px, py, dx, dy, dz, off_x, off_y);
+    gen_primary_dir(ipv.m, near_, far_, width, height, px, py, dx, dy, dz, off_x, off_y);
     dir_out[3 * (size_t)i + 0] = dx; dir_out[3 * (size_t)i + 1] = dy; dir_out[3 * (size_t)i + 2] = dz;
 }
 

@@ -71,7 +71,6 @@ struct rtamd_context {
     DevBuf materials, tex_slots;
     uint32_t n_materials = 0;
     uint32_t scene_max_mat = 0;       // largest mat_idx of the uploaded scene's triangles
-    DevBuf ipv;  // 16 floats for k_generate_rays
 #ifdef RTAMD_EXP_STAMPS
     DevBuf stamps;
 #endif
@@ -448,7 +447,6 @@ int rtamd_context_create(int device_ordinal, rtamd_context **out_ctx) {
         rtamd_context::Slot *sl = nullptr;
         if ((rc = acquire_slot(ctx, &sl))) return bail(rc);
     }
-    if ((rc = dev_alloc(ctx, ctx->ipv, 64))) return bail(rc);
     *out_ctx = ctx;
     return RTAMD_OK;
 }
@@ -460,7 +458,7 @@ void rtamd_context_destroy(rtamd_context *ctx) {
     (void)hipDeviceSynchronize();   // launches may be in flight on several (caller-owned) streams
     ctx->nodes.release(); ctx->tris.release(); ctx->big.release(); ctx->tri_idx.release();
     ctx->normals.release(); ctx->texcoords.release(); for (auto &t : ctx->tex) t.release(); ctx->materials.release(); ctx->tex_slots.release(); ctx->noise.release();
-    ctx->white.release(); ctx->ipv.release();
+    ctx->white.release();
     for (auto &sl : ctx->slots) {
         sl.queues.release(); sl.spill.release();
         if (sl.ev_start) (void)hipEventDestroy(sl.ev_start);
@@ -1038,6 +1036,7 @@ int rtamd_trace(rtamd_context *ctx, uint64_t n, const float *org, const float *d
     if (!ctx->has_scene) return fail(ctx, RTAMD_ERR_NO_SCENE, "no scene uploaded");
     if (n == 0) return RTAMD_OK;
     if (!org || !dir || !hits) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "org / dir / hits is NULL");
+    if (n > 0xFFFFFFFFull) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "at most 2^32-1 rays per call");
     DeviceScope dev_scope;
     int rc = dev_scope.enter(ctx);
     if (rc) return rc;
@@ -1065,13 +1064,14 @@ int rtamd_generate_rays_offset_device(rtamd_context *ctx, uint32_t width, uint32
     int rc = dev_scope.enter(ctx);
     if (rc) return rc;
     if ((rc = check_range(ctx, dir_out, (uint64_t)width * height * 12, "dir_out"))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->ipv.p, inv_proj_view, 64, hipMemcpyHostToDevice, ctx->stream));
+    // the matrix travels in the kernel arguments: nothing of the caller's memory is read after return, and the call
+    // does not wait for the stream (round 1 staged it through one device buffer and had to synchronise per call)
+    Mat4Arg ipv;
+    std::memcpy(ipv.m, inv_proj_view, sizeof ipv.m);
     uint32_t n = width * height;
-    hipLaunchKernelGGL(k_generate_rays, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const float *)ctx->ipv.p, near_plane, far_plane, width, height,
+    hipLaunchKernelGGL(k_generate_rays, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ipv, near_plane, far_plane, width, height,
                        offset_x, offset_y, dir_out);
     HIP_TRY(ctx, hipGetLastError());
-    // inv_proj_view is a host pointer that may die after return, and ctx->ipv is one staging buffer: make the copy complete
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RTAMD_OK;
 }
 
@@ -1105,6 +1105,7 @@ int rtamd_surface_from_hits(rtamd_context *ctx, uint64_t n, const float *org, co
     if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
     if (n == 0) return RTAMD_OK;
     if (!org || !dir || !hits || !position || !normal_mat) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "surface_from_hits: NULL buffer");
+    if (n > 0xFFFFFFFFull) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "at most 2^32-1 rays per call");
     DeviceScope dev_scope;
     int rc = dev_scope.enter(ctx);
     if (rc) return rc;
@@ -1135,8 +1136,9 @@ int rtamd_generate_rays(rtamd_context *ctx, uint32_t width, uint32_t height, con
     if ((rc = dev_alloc(ctx, d, bytes))) return rc;
     rc = rtamd_generate_rays_device(ctx, width, height, inv_proj_view, near_plane, far_plane, (float *)d.p);
     if (!rc) {
-        hipError_t e = hipMemcpy(dir_out, d.p, bytes, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(ctx, RTAMD_ERR_DEVICE, "copy-back failed: %s", hipGetErrorString(e));
+        hipError_t e = hipStreamSynchronize(ctx->stream);   // the context's stream does not synchronise with the copy's null stream
+        if (e == hipSuccess) e = hipMemcpy(dir_out, d.p, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(ctx, RTAMD_ERR_DEVICE, "generate_rays failed: %s", hipGetErrorString(e));
     }
     d.release();
     return rc;

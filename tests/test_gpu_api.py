@@ -661,28 +661,48 @@ def test_config1_f16_640x480_matches_oracle(tracer, oracle_a):
 
 def test_device_buffers_are_range_checked(tracer):
     """A "_device" call whose buffer would run past the end of the device allocation it starts in is refused on the host
-    (rtamd_set_option "validate_buffers", default on) instead of faulting on the GPU."""
-    import torch
+    (rtamd_set_option "validate_buffers", default on) instead of faulting on the GPU.  The buffers come straight from
+    hipMalloc, one allocation each: a tensor of torch's caching allocator may sit inside a larger cached block, where
+    running past the tensor is not running past the allocation (the check's documented limit)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def dev_alloc(nbytes, host=None):
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(nbytes)) == 0
+        if host is None:
+            assert hip.hipMemset(p, 0, ctypes.c_size_t(nbytes)) == 0
+        else:
+            assert host.nbytes == nbytes and hip.hipMemcpy(p, host.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(nbytes), 1) == 0
+        return p.value
+
     g = load_golden("cube")
     tracer.upload_scene(g["scene"])
-    dev = torch.device("cuda", 0)
-    w = h = 2048                                           # 48 MiB of rays: an allocation of its own in torch's caching allocator
-    rays = torch.zeros((w * h, 3), dtype=torch.float32, device=dev)
-    rays[:, 2] = -1.0
-    out = torch.zeros((w * (h + 1), 4), dtype=torch.float32, device=dev)
-    tracer.render_device(w, h, rays.data_ptr(), rays.data_ptr(), rgba_ptr=out.data_ptr())           # fits
-    tracer.synchronize()
-    with pytest.raises(RtamdError) as e:                   # one more row of pixels than the ray buffers hold
-        tracer.render_device(w, h + 1, rays.data_ptr(), rays.data_ptr(), rgba_ptr=out.data_ptr())
-    assert e.value.code == -1 and "run past the end" in str(e.value)
-    with pytest.raises(RtamdError):
-        tracer.render_device_static(w, h + 1, rays.data_ptr(), rays.data_ptr(), rgba_ptr=out.data_ptr())
-    with pytest.raises(RtamdError):
-        tracer.render_batch_device(w, h + 1, [{"dir_ptr": rays.data_ptr(), "org_ptr": rays.data_ptr(), "rgba_ptr": out.data_ptr()}] * 2)
-    hits = torch.zeros((w * h, 4), dtype=torch.float32, device=dev)
-    with pytest.raises(RtamdError):
-        tracer.trace_device(w * h + 64, rays.data_ptr(), rays.data_ptr(), hits.data_ptr())
-    with pytest.raises(RtamdError):
-        tracer.trace_device(w * h, rays.data_ptr(), rays.data_ptr(), hits.data_ptr() + 16 * 4096)     # output shifted past its end
-    tracer.trace_device(w * h, rays.data_ptr(), rays.data_ptr(), hits.data_ptr())
-    tracer.synchronize()
+    w = h = 512
+    host_rays = np.zeros((w * h, 3), np.float32)
+    host_rays[:, 2] = -1.0
+    rays = dev_alloc(w * h * 12, host_rays)
+    out = dev_alloc(w * (h + 1) * 16)
+    hits = dev_alloc(w * h * 16)
+    try:
+        tracer.render_device(w, h, rays, rays, rgba_ptr=out)           # fits
+        tracer.synchronize()
+        with pytest.raises(RtamdError) as e:                   # one more row of pixels than the ray buffers hold
+            tracer.render_device(w, h + 1, rays, rays, rgba_ptr=out)
+        assert e.value.code == -1 and "run past the end" in str(e.value)
+        with pytest.raises(RtamdError):
+            tracer.render_device_static(w, h + 1, rays, rays, rgba_ptr=out)
+        with pytest.raises(RtamdError):
+            tracer.render_batch_device(w, h + 1, [{"dir_ptr": rays, "org_ptr": rays, "rgba_ptr": out}] * 2)
+        with pytest.raises(RtamdError):
+            tracer.trace_device(w * h + 64, rays, rays, hits)
+        with pytest.raises(RtamdError):
+            tracer.trace_device(w * h, rays, rays, hits + 16 * 4096)     # output shifted past its end
+        with pytest.raises(RtamdError):
+            tracer.render_device(w, h, rays + 12 * w, rays, rgba_ptr=out)   # ray buffer entered one row late
+        tracer.trace_device(w * h, rays, rays, hits)
+        tracer.synchronize()
+    finally:
+        tracer.synchronize()
+        for p in (rays, out, hits):
+            assert hip.hipFree(ctypes.c_void_p(p)) == 0

@@ -37,6 +37,7 @@ def main():
     n = W * H
     d_dir = torch.empty((n, 3), dtype=torch.float32, device=dev)
     tr.generate_rays_device(W, H, camera.inv_proj_view(), d_dir.data_ptr())
+    tr.synchronize()
     d_org = torch.tensor(np.asarray(camera.position, np.float32), device=dev).repeat(n, 1).contiguous()
     d_rgba = torch.zeros((n, 4), dtype=torch.float32, device=dev)
     d_hits = torch.zeros((n, 4), dtype=torch.float32, device=dev)

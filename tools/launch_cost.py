@@ -8,7 +8,7 @@ sc = model.scene_arrays(); dev = torch.device("cuda", 0)
 tr = HipRayTracer(0); tr.upload_scene(sc)
 for slot, t in enumerate(tex): tr.upload_texture(slot, t)
 n = W * H
-d_dir = torch.empty((n, 3), dtype=torch.float32, device=dev); tr.generate_rays_device(W, H, camera.inv_proj_view(), d_dir.data_ptr())
+d_dir = torch.empty((n, 3), dtype=torch.float32, device=dev); tr.generate_rays_device(W, H, camera.inv_proj_view(), d_dir.data_ptr()); tr.synchronize()
 d_org = torch.tensor(np.asarray(camera.position, np.float32), device=dev).repeat(n, 1).contiguous()
 streams = [torch.cuda.Stream(device=dev) for _ in range(8)]
 timing = int(os.environ.get("LAUNCH_TIMING", "1"))

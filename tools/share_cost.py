@@ -22,7 +22,7 @@ for slot, t in enumerate(tex):
         tr.upload_texture(slot, t)
 n = W * H
 d_dir = torch.empty((n, 3), dtype=torch.float32, device=dev)
-tr.generate_rays_device(W, H, camera.inv_proj_view(), d_dir.data_ptr())
+tr.generate_rays_device(W, H, camera.inv_proj_view(), d_dir.data_ptr()); tr.synchronize()
 d_org = torch.tensor(np.asarray(camera.position, np.float32), device=dev).repeat(n, 1).contiguous()
 has_tc, has_n = model.has_tex_coords(), model.has_normals()
 streams = [torch.cuda.Stream(device=dev) for _ in range(4)]

@@ -17,7 +17,7 @@ tr = HipRayTracer(0); tr.upload_scene(sc)
 for slot, t in enumerate(tex):
     if t is not None: tr.upload_texture(slot, t)
 n = W * H
-d_dir = torch.empty((n, 3), dtype=torch.float32, device=dev); tr.generate_rays_device(W, H, camera.inv_proj_view(), d_dir.data_ptr())
+d_dir = torch.empty((n, 3), dtype=torch.float32, device=dev); tr.generate_rays_device(W, H, camera.inv_proj_view(), d_dir.data_ptr()); tr.synchronize()
 d_org = torch.tensor(np.asarray(camera.position, np.float32), device=dev).repeat(n, 1).contiguous()
 d_rgba = torch.zeros((n, 4), dtype=torch.float32, device=dev)
 tr.set_option('leaf_thresh', 8)
