@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""The streaming kernels around the traversal (GPU box): each against the HBM roofline, at 1080p and 4K.
+Algorithmic bytes per pixel / ray (what the call must move at least):
+  k_generate_rays       ray_create.frag          12 out
+  k_surface_from_hits   rasteriser G-buffer pass 12 org + 12 dir + 16 hit in, 12 + 16 out  (+ the hit triangle's index record and
+                                                 three normals, gathered: cache-served for neighbouring pixels, not counted)
+  k_dispatch_rays       ray_dispatcher.frag      12 + 16 in, 4 x 12 out
+  k_display_rgba8       util/display.frag        16 in, 4 out
+  k_assemble_tiles      root side of the gather  16 in, 16 out (RGBA32F) or 4 + 4 (RGBA8)
+Prints one JSON line per kernel and frame size."""
+import json
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from raytracer_amd.renderer import HipRayTracer  # noqa: E402
+
+dev = torch.device("cuda", 0)
+tr = HipRayTracer(0)
+model, camera, _, _, tex = bench.build_workload("atrium_1080p")
+tr.upload_scene(model.scene_arrays())
+rng = np.random.default_rng(3)
+v = rng.normal(size=(512, 512, 3))
+v /= np.linalg.norm(v, axis=-1, keepdims=True)
+tr.upload_noise_texture(np.clip(np.round((v * 0.5 + 0.5) * 255), 0, 255).astype(np.uint8))
+st = torch.cuda.Stream(device=dev)
+tr.set_stream(st.cuda_stream)
+
+
+def timed(fn, reps=100):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(reps):
+        fn()
+    e1.record(st)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def report(kernel, w, h, ms, bytes_per_px, note=""):
+    n = w * h
+    gbs = bytes_per_px * n / (ms * 1e-3) / 1e9
+    print(json.dumps({"kernel": kernel, "frame": f"{w}x{h}", "ms": round(ms, 4), "bytes_per_pixel": bytes_per_px, **({"note": note} if note else {}),
+                      "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)}}), flush=True)
+
+
+for w, h in ((1920, 1080), (3840, 2160)):
+    n = w * h
+    camera.aspect = w / h
+    inv = camera.inv_proj_view()
+    f = lambda c, dt=torch.float32: torch.empty((n, c), dtype=dt, device=dev)   # noqa: E731
+    d_dir, d_hits, d_pos, d_nm = f(3), f(4), f(3), f(4)
+    d_org = torch.tensor(np.asarray(camera.position, np.float32), device=dev).repeat(n, 1).contiguous()
+    outs = [f(3) for _ in range(4)]
+    rgba = torch.rand((n, 4), dtype=torch.float32, device=dev)
+    rgba8 = torch.empty((n,), dtype=torch.int32, device=dev)
+    report("k_generate_rays", w, h, timed(lambda: tr.generate_rays_device(w, h, inv, d_dir.data_ptr())), 12)
+    tr.trace_device(n, d_org.data_ptr(), d_dir.data_ptr(), d_hits.data_ptr())
+    tr.synchronize()
+    report("k_surface_from_hits", w, h, timed(lambda: tr.surface_from_hits_device(n, d_org.data_ptr(), d_dir.data_ptr(), d_hits.data_ptr(), 1, d_pos.data_ptr(), d_nm.data_ptr())), 68,
+           "camera-ray hit records of the atrium; gathers of the triangle record and three normals not counted")
+    args = (w, h, d_pos.data_ptr(), d_nm.data_ptr(), (0.0, 12.0, 0.0), tuple(float(x) for x in camera.position), (5 / 512, 9 / 512, w / 512, h / 512))
+    kw = dict(org_ptr=outs[0].data_ptr(), shadow_dir_ptr=outs[1].data_ptr(), reflect_dir_ptr=outs[2].data_ptr(), ambient_dir_ptr=outs[3].data_ptr())
+    report("k_dispatch_rays", w, h, timed(lambda: tr.dispatch_rays_device(*args, **kw)), 76)
+    report("k_display_rgba8", w, h, timed(lambda: tr.display_rgba8_device(rgba.data_ptr(), n, rgba8.data_ptr())), 20)
+    for world in (2, 8):
+        per = tr.tiles_per_rank(w, h, world) * 1024
+        src = torch.rand((world * per, 4), dtype=torch.float32, device=dev)
+        dst = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        report("k_assemble_tiles", w, h, timed(lambda: tr.assemble_tiles_device(src.data_ptr(), w, h, world, 4, dst.data_ptr())), 32, f"RGBA32F shares of {world} ranks")
+        src8 = torch.randint(0, 2**31 - 1, (world * per,), dtype=torch.int32, device=dev)
+        dst8 = torch.empty((n,), dtype=torch.int32, device=dev)
+        report("k_assemble_tiles", w, h, timed(lambda: tr.assemble_tiles_device(src8.data_ptr(), w, h, world, 1, dst8.data_ptr())), 8, f"RGBA8 shares of {world} ranks")
