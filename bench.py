@@ -239,8 +239,9 @@ def main():
         # (16 per launch: 33 us).  Auto: a launch of about two whole frames' work — 8 frames up to 4 ranks, 16 beyond
         B = args.gather_batch if args.gather_batch > 0 else (args.batch if args.batch > 0 else ((8 if world <= 4 else 16) if n_px <= 1920 * 1080 else 2))
     else:
-        # 8 frames per launch, 4 for short runs (a 20-step run then still has five launches to alternate over the two streams)
-        B = args.batch if args.batch > 0 else (2 if scene_mb > 256 else 8 if args.steps >= 64 else 4)
+        # 8 frames per launch (a 20-step run: 8 + 8 + 4, measured equal to five launches of 4 — 0.240 ms per frame — with the
+        # per-launch figures of the steady state); 4 only for runs shorter than two such launches
+        B = args.batch if args.batch > 0 else (2 if scene_mb > 256 else 8 if args.steps >= 16 else 4)
     B = max(1, min(16, B))
     if args.variant != 0:
         B = 1
@@ -267,24 +268,6 @@ def main():
             frames_out = torch.empty((B, n_px, 4), dtype=torch.float32, device=dev)
         frame = frames_out[0]
     launch_events = []     # (frames in the launch, start event, stop event)
-    if S == 2 and world == 1:
-        # two streams that share a hardware queue cannot overlap (HIP spreads a process's streams over GPU_MAX_HW_QUEUES
-        # queues): try a handful of partner streams and keep the one that overlaps best with the main stream
-        def pair_ms(partner, batches=6):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for k in range(batches):
-                tracer.set_stream((stream, partner)[k % 2].cuda_stream)
-                tracer.render_batch_device(W, H, [{"dir_ptr": d_dir.data_ptr(), "org_ptr": d_org.data_ptr(), "rgba_ptr": rgba[k % 2].data_ptr() + g * n_local_out * 16}
-                                                  for g in range(B)], has_tex_coords=has_tc, has_normals=has_n)
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / batches
-        candidates = [render_streams[1]] + [torch.cuda.Stream(device=dev) for _ in range(3)]
-        for c in candidates:
-            pair_ms(c, 2)   # first use of a stream creates its queue
-        render_streams[1] = min(candidates, key=pair_ms)
-        tracer.set_stream(stream.cuda_stream)
-
     def launch(f, n_frames, timed):
         """Frames 0..n_frames-1 of batch buffer f in ONE launch on render_streams[f]."""
         rs = render_streams[f]
@@ -360,6 +343,28 @@ def main():
         dist.all_reduce(stats)
     n_primary_all, n_shadow_all, n_box_all, n_tri_all = (int(x) for x in stats.tolist())
     rays_per_frame = n_primary_all + n_shadow_all
+
+    # ---- untimed: pick the partner stream.  This is the last piece of set-up on purpose: it renders about a hundred frames, so the
+    # warm-up that follows starts from a loaded GPU (a 20-step run after an idle gap measures the clock ramp: 0.261 ms per frame against
+    # 0.249 after 50 warm-up frames and 0.245 after 500, same code)
+    if S == 2 and args.variant == 0:
+        # two streams that share a hardware queue cannot overlap (HIP spreads a process's streams over GPU_MAX_HW_QUEUES
+        # queues): try a handful of partner streams and keep the one that overlaps best with the first render stream
+        # (every rank for itself, on its own tile share: no collective here)
+        def pair_ms(partner, batches=6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(batches):
+                tracer.set_stream((render_streams[0], partner)[k % 2].cuda_stream)
+                tracer.render_batch_device(W, H, [{"dir_ptr": d_dir.data_ptr(), "org_ptr": d_org.data_ptr(), "rgba_ptr": rgba[k % 2].data_ptr() + g * n_local_out * 16}
+                                                  for g in range(B)], has_tex_coords=has_tc, has_normals=has_n, tile_rank=rank, tile_world=world)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / batches
+        candidates = [render_streams[1]] + [torch.cuda.Stream(device=dev) for _ in range(3)]
+        for c in candidates:
+            pair_ms(c, 2)   # first use of a stream creates its queue
+        render_streams[1] = min(candidates, key=pair_ms)
+        tracer.set_stream(stream.cuda_stream)
 
     # ---- warmup + timed region
     tracer.set_stream(stream.cuda_stream)
