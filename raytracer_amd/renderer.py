@@ -26,7 +26,6 @@ def reference_material(texture_slot):
     return ((0.5, 0.5, 0.5), (0.8, 0.8, 0.8), (0.4, 0.4, 0.4), 30.0, texture_slot)
 
 
-
 class RtamdError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"rtamd error {code}: {message}")
@@ -100,6 +99,9 @@ class HipRayTracer:
         nr = None if nr is None else np.ascontiguousarray(nr, dtype=np.float32)
         if nodes.size and nodes.dtype.itemsize != 36 or tris.size and tris.dtype.itemsize != 16:
             raise ValueError("nodes must be 36-byte and triangles 16-byte records")
+        # the C-ABI takes pointers and ONE vertex count (as the reference's SSBOs do): the per-vertex streams must agree with it
+        if pos.size % 3 or (tc is not None and tc.size != 2 * (pos.size // 3)) or (nr is not None and nr.size != pos.size):
+            raise ValueError("positions must be (V, 3), tex_coords (V, 2) and normals (V, 3) for the same V")
         d = _ffi.SceneDesc(nodes.ctypes.data if nodes.size else None, len(nodes), tris.ctypes.data if tris.size else None, len(tris),
                            pos.ctypes.data if pos.size else None, pos.size // 3,
                            None if tc is None else tc.ctypes.data, None if nr is None else nr.ctypes.data)
@@ -185,7 +187,7 @@ class HipRayTracer:
         self._check(self._lib.rtamd_render_device(self._h, ctypes.byref(d), ctypes.byref(o)))
 
     def render_batch_device(self, width, height, frames, has_tex_coords=False, has_normals=False, tile_rank=0, tile_world=1):
-        """rtamd_render_batch_device: up to 8 frames in one launch.  frames: a sequence of dicts with the per-frame
+        """rtamd_render_batch_device: up to 16 frames (RTAMD_MAX_BATCH_FRAMES) in one launch.  frames: a sequence of dicts with the per-frame
         keyword arguments of render_device (dir_ptr, org_ptr | camera; rgba_ptr, hit_id_ptr, hit_t_ptr, counts_ptr, rgba8_ptr)."""
         n = len(frames)
         descs = (_ffi.FrameDesc * n)()

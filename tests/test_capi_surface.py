@@ -76,3 +76,31 @@ def test_abi_version_of_header_library_and_bindings_agree():
     lib = ctypes.CDLL(_ffi.DEVICE_LIB_PATH)
     lib.rtamd_abi_version.restype = ctypes.c_uint32
     assert v == _ffi.ABI_VERSION == lib.rtamd_abi_version()
+
+
+def test_ctypes_struct_layouts_equal_the_headers(tmp_path):
+    """Every struct the Python bindings declare (raytracer_amd/_ffi.py, renderer.SHADING_MATERIAL_DTYPE) has the size and the
+    field offsets a C compiler gives the declaration in include/rtamd.h."""
+    import subprocess
+    from raytracer_amd import _ffi, renderer
+    pairs = {"rtamd_scene_desc": _ffi.SceneDesc, "rtamd_frame_desc": _ffi.FrameDesc, "rtamd_frame_out": _ffi.FrameOut,
+             "rtamd_dispatch_desc": _ffi.DispatchDesc, "rtamd_dispatch_out": _ffi.DispatchOut, "rtamd_scene_info": _ffi.SceneInfo}
+    lines = []
+    for cname, cls in pairs.items():
+        lines.append(f'printf("{cname} %zu", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf(" %zu", offsetof({cname}, {fname}));')
+        lines.append('printf("\\n");')
+    mat_fields = renderer.SHADING_MATERIAL_DTYPE.names
+    lines.append('printf("rtamd_shading_material %zu", sizeof(rtamd_shading_material));')
+    lines += [f'printf(" %zu", offsetof(rtamd_shading_material, {f}));' for f in mat_fields] + ['printf("\\n");']
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "rtamd.h"\nint main(void) {\n' + "\n".join(lines) + "\nreturn 0;\n}\n")
+    exe = str(tmp_path / "layout")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(REPO, "include"), str(src), "-o", exe], check=True)
+    out = {ln.split()[0]: [int(x) for x in ln.split()[1:]] for ln in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines()}
+    for cname, cls in pairs.items():
+        want = [ctypes.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
+        assert out[cname] == want, (cname, out[cname], want)
+    dt = renderer.SHADING_MATERIAL_DTYPE
+    assert out["rtamd_shading_material"] == [dt.itemsize] + [dt.fields[f][1] for f in mat_fields]
