@@ -17,11 +17,15 @@ BIN = os.path.join(REPO, "tests", "c_caller", "drop_in")         # built by __gr
 LIB_DIR = os.path.join(REPO, "raytracer_amd", "lib")
 
 
-def test_c99_caller_compiles_strictly_and_fails_loudly_without_a_gpu(tmp_path):
-    import torch
-    exe = str(tmp_path / "drop_in")
+def _compile(exe):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(REPO, "include"), SRC, "-L" + LIB_DIR, "-lrtamd",
                     "-Wl,-rpath," + LIB_DIR, "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe], check=True)
+    return exe
+
+
+def test_c99_caller_compiles_strictly_and_fails_loudly_without_a_gpu(tmp_path):
+    import torch
+    exe = _compile(str(tmp_path / "drop_in"))
     assert os.path.exists(BIN), "tests/c_caller/drop_in not built: run __graft_entry__.build()"
     if torch.cuda.is_available():
         pytest.skip("GPU present: the run is test_c_caller_renders_the_reference_pixels")
@@ -49,13 +53,14 @@ def _write_scene(path, g):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["f16", "teapot"])
 def test_c_caller_renders_the_reference_pixels(tmp_path, name):
-    assert os.path.exists(BIN), "tests/c_caller/drop_in not built: run __graft_entry__.build()"
+    # the binary __graft_entry__.build() made travels with the tree; a tree without it gets a fresh one (a 0.2 s gcc run, no HIP)
+    exe = BIN if os.path.exists(BIN) else _compile(str(tmp_path / "drop_in"))
     g = load_golden(name)
     h, w = g["dir"].shape[:2]
     n = w * h
     scene, out = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")
     _write_scene(scene, g)
-    p = subprocess.run([BIN, scene, out], capture_output=True, text=True, timeout=120)
+    p = subprocess.run([exe, scene, out], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and p.stdout.startswith("ok:"), (p.returncode, p.stdout, p.stderr)
     raw = np.fromfile(out, np.uint8)
     assert raw.size == n * (16 + 4 + 4 + 4 + 16)
