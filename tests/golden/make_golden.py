@@ -23,7 +23,7 @@ inputs + outputs as compressed .npz files:
   golden_raycreate.npz: ray_trace/ray_create.frag for three cameras (inputs + RGB32F direction target)
   golden_soup.npz: the same as golden_atrium for a 100 000-triangle seeded soup (camera frame + 8192 random rays)
 
-The fixtures are data only.  Usage:  python tests/golden/make_golden.py [--only-atrium | --only-soup | --only-raycreate | --only-more-models | --add-uniform]
+The fixtures are data only.  Usage:  python tests/golden/make_golden.py [--only-atrium | --only-soup | --only-raycreate | --only-more-models | --only-dispatch2 | --add-uniform]
 """
 import math
 import os
@@ -227,6 +227,30 @@ def main(cases=FIRST_CASES, with_extras=True):
     print("special:", int((b_trace[..., 0] < 1e30).sum()), "hits of", hh * ww)
 
 
+def dispatch2():
+    """A second dispatcher fixture (round 2): ray_dispatcher.frag on the G-buffer of the f16 frame — interpolated vertex normals
+    and two materials, made from the committed b_trace records by the oracle's restatement of the rasteriser pass — with the
+    reference's own 512 x 512 blue-noise image (res/textures/blue_noise.png), a light below the model, the camera of the frame and
+    a texel-grid offset in both axes.  Stored like golden_dispatch.npz; the noise travels as a 128 x 128 crop."""
+    from oracles import OracleA
+    B, A = OracleB(), OracleA()
+    g = dict(np.load(os.path.join(HERE, "golden_f16.npz")))
+    sc = {"nodes": g["nodes"], "triangles": g["triangles"], "positions": g["positions"], "tex_coords": g["tex_coords"], "normals": g["normals"]}
+    h, w = g["dir"].shape[:2]
+    pos, nm = A.surface_from_hits(sc, g["org"], g["dir"], g["b_trace"], 1)
+    gpos, gnm = pos.reshape(h, w, 3), nm.reshape(h, w, 4)
+    noise = load_rgb(os.path.join(REF, "textures", "blue_noise.png"))[192:320, 64:192].copy()
+    light = np.array([-6.0, -9.0, 2.5], np.float32)
+    cam_pos = g["org"][0, 0].astype(np.float32)
+    nos = np.array([37 / 128, 101 / 128, w / 128, h / 128], np.float32)
+    d = B.dispatch(gpos, gnm, noise, light, cam_pos, nos)
+    path = os.path.join(HERE, "golden_dispatch2.npz")
+    np.savez_compressed(path, position=gpos, normal_mat=gnm, noise=noise, light_pos=light, camera_pos=cam_pos, noise_offset_scale=nos,
+                        b_org=d["org"], b_shadow_dir=d["shadow_dir"], b_reflect_dir=d["reflect_dir"], b_ambient_dir=d["ambient_dir"], renderer=np.array(B.renderer))
+    surface = gnm[..., 3] != np.float32(1e30)
+    print("dispatch2:", int(surface.sum()), "surface pixels of", w * h, "materials", np.unique(gnm[..., 3][surface].view(np.uint32)), "->", os.path.getsize(path) / 1e6, "MB")
+
+
 def atrium():
     """The headline scene (bench.py's atrium_1080p, BASELINE config 3) at 240x135: the scene is procedural and
     deterministic (raytracer_amd/scenes.py + the host BVH builder), so only the shader outputs are stored; the
@@ -302,6 +326,8 @@ def raycreate():
 if __name__ == "__main__":
     if "--add-uniform" in sys.argv:
         add_uniform_to_existing()
+    elif "--only-dispatch2" in sys.argv:
+        dispatch2()
     elif "--only-more-models" in sys.argv:
         main(MORE_CASES, with_extras=False)
     elif "--only-raycreate" in sys.argv:

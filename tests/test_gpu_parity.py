@@ -127,10 +127,12 @@ def test_ray_creation_matches_reference_shader(tracer):
     check_raycreate(gen)
 
 
-def test_ray_dispatcher_matches_reference_shader(tracer, oracle_a):
-    """k_dispatch_rays vs ray_dispatcher.frag on llvmpipe (fixture) and vs oracle A, through the host
-    entry point; then ragged sizes (partial last block, sizes below one block) vs oracle A bit for bit."""
-    g = load_golden("dispatch")
+@pytest.mark.parametrize("fixture", ["dispatch", "dispatch2"])
+def test_ray_dispatcher_matches_reference_shader(tracer, oracle_a, fixture):
+    """k_dispatch_rays vs ray_dispatcher.frag on llvmpipe (two fixtures: bunny frame / seeded noise, f16 frame / the
+    reference's blue noise) and vs oracle A, through the host entry point; then ragged sizes (partial last block, sizes
+    below one block) vs oracle A bit for bit."""
+    g = load_golden(fixture)
     tracer.upload_noise_texture(g["noise"])
     args = (g["light_pos"], g["camera_pos"], g["noise_offset_scale"])
     r = tracer.dispatch_rays(g["position"], g["normal_mat"], *args)
