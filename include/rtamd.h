@@ -53,7 +53,7 @@ typedef struct rtamd_context rtamd_context;
  * ray_trace_and_shade.frag:201,232-234). */
 /* Bumped whenever a struct layout or the meaning of an argument changes; a binder compares its compile-time
  * value with rtamd_abi_version() of the library it loaded.  (No counterpart in the reference.) */
-#define RTAMD_ABI_VERSION 6
+#define RTAMD_ABI_VERSION 7
 uint32_t rtamd_abi_version(void);
 
 #define RTAMD_NO_HIT 0xFFFFFFFFu
@@ -252,6 +252,14 @@ int rtamd_generate_rays_device(rtamd_context *ctx, uint32_t width, uint32_t heig
 int rtamd_generate_rays_offset_device(rtamd_context *ctx, uint32_t width, uint32_t height, const float inv_proj_view[16],
                                       float near_plane, float far_plane, float offset_x, float offset_y, float *dir_out);
 
+/* As rtamd_generate_rays_offset_device for one rank's tile shard of the frame (BASELINE config 5 split over GPUs: the
+ * samples of a pixel stay on the GPU that owns its tile): dir_out holds rtamd_tiles_per_rank-style local tiles * 1024
+ * rays in the compact tile-major layout, entries outside the frame are (0,0,0) = NO_RAY.  tile_world == 1 is
+ * rtamd_generate_rays_offset_device.  No counterpart in the reference (one GPU, one sample). */
+int rtamd_generate_rays_tiles_device(rtamd_context *ctx, uint32_t width, uint32_t height, const float inv_proj_view[16],
+                                     float near_plane, float far_plane, float offset_x, float offset_y,
+                                     uint32_t tile_rank, uint32_t tile_world, float *dir_out);
+
 /* ---- hit records -> G-buffer ------------------------------------------------ */
 
 /* For ray i with hit record hits[4i..] = (t, u, v, bits(idx)) (rtamd_trace): position[3i..] = org + dir * t,
@@ -279,6 +287,11 @@ typedef struct rtamd_dispatch_desc {
     float light_pos[3];           /* uniform 3 */
     float camera_pos[3];          /* uniform 4 */
     float noise_offset_scale[4];  /* uniform 5: xy offset, zw scale (src/main.rs:161-166) */
+    /* Tile shard (rtamd_dispatch_rays_device only; ABI 7): with tile_world > 1 the G-buffer and the four targets hold this
+     * rank's tiles in the compact tile-major layout of rtamd_frame_out (local tiles * 1024 entries), and an entry's
+     * noise texel is the one of its pixel in the whole frame, so a shard's rays are bit for bit the whole frame's.
+     * Entries of edge tiles outside the frame are "no surface".  tile_world 0 or 1: the whole frame, scan-line order. */
+    uint32_t tile_rank, tile_world;
 } rtamd_dispatch_desc;
 
 typedef struct rtamd_dispatch_out {

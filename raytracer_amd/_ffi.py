@@ -69,6 +69,7 @@ class DispatchDesc(ctypes.Structure):
         ("position", ctypes.c_void_p), ("normal_mat", ctypes.c_void_p),
         ("light_pos", ctypes.c_float * 3), ("camera_pos", ctypes.c_float * 3),
         ("noise_offset_scale", ctypes.c_float * 4),
+        ("tile_rank", ctypes.c_uint32), ("tile_world", ctypes.c_uint32),
     ]
 
 
@@ -136,7 +137,7 @@ def host_lib():
     return _host
 
 
-ABI_VERSION = 6   # include/rtamd.h RTAMD_ABI_VERSION
+ABI_VERSION = 7   # include/rtamd.h RTAMD_ABI_VERSION
 
 
 def device_lib():
@@ -192,6 +193,9 @@ def device_lib():
         L.rtamd_generate_rays_offset_device.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, c_float_p, ctypes.c_float, ctypes.c_float,
                                                         ctypes.c_float, ctypes.c_float, vp]
         L.rtamd_generate_rays_offset_device.restype = ctypes.c_int
+        L.rtamd_generate_rays_tiles_device.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, c_float_p, ctypes.c_float, ctypes.c_float,
+                                                       ctypes.c_float, ctypes.c_float, ctypes.c_uint32, ctypes.c_uint32, vp]
+        L.rtamd_generate_rays_tiles_device.restype = ctypes.c_int
         L.rtamd_last_launch_coherence.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint32)]
         L.rtamd_last_launch_coherence.restype = ctypes.c_int
         L.rtamd_upload_noise_texture.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint32]

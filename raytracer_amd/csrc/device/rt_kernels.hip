@@ -581,6 +581,19 @@ __device__ __forceinline__ PixelRef item_pixel(const JobParams &p, uint32_t item
     return r;
 }
 
+// Pixel of entry i of a rank's buffer: scan-line order for world <= 1, else the compact tile-major layout of
+// include/rtamd.h (local tile j = i / 1024 is global tile j * world + rank, row-major 32 x 32 inside the tile).
+// false: the entry lies in the part of an edge tile that is outside the frame.
+__device__ __forceinline__ bool shard_pixel(uint32_t i, uint32_t width, uint32_t height, uint32_t rank, uint32_t world, uint32_t tiles_x,
+                                            uint32_t &px, uint32_t &py) {
+    if (world <= 1u) { px = i % width; py = i / width; return true; }
+    const uint32_t j = i >> 10, within = i & 1023u;
+    const uint32_t g = j * world + rank;
+    px = (g % tiles_x) * 32u + (within & 31u);
+    py = (g / tiles_x) * 32u + (within >> 5);
+    return px < width && py < height;
+}
+
 // ---------------------------------------------------------------------------
 // queues: n_queues counters (queue_stride words apart) over ONE schedule, the items in
 // their natural (tile) order.  A wave starts on the counter of its XCD and steals from the
@@ -998,12 +1011,13 @@ __global__ void __launch_bounds__(BLOCK) k_static(const SceneDev s, const JobPar
 // ---------------------------------------------------------------------------
 struct Mat4Arg { float m[16]; };   // inverse(proj * view), column-major, by value in the kernel arguments (scalar loads, no staging buffer)
 __global__ void k_generate_rays(const Mat4Arg ipv, float near_, float far_, uint32_t width, uint32_t height, float off_x, float off_y,
-                                float *__restrict__ dir_out) {
+                                uint32_t rank, uint32_t world, uint32_t tiles_x, uint32_t n, float *__restrict__ dir_out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= width * height) return;
-    uint32_t px = i % width, py = i / width;
-    float dx, dy, dz;
-    gen_primary_dir(ipv.m, near_, far_, width, height, px, py, dx, dy, dz, off_x, off_y);
+    if (i >= n) return;
+    uint32_t px, py;
+    float dx = 0.0f, dy = 0.0f, dz = 0.0f;      // outside the frame: NO_RAY (ray_trace.frag:6)
+    if (shard_pixel(i, width, height, rank, world, tiles_x, px, py))
+        gen_primary_dir(ipv.m, near_, far_, width, height, px, py, dx, dy, dz, off_x, off_y);
     dir_out[3 * (size_t)i + 0] = dx; dir_out[3 * (size_t)i + 1] = dy; dir_out[3 * (size_t)i + 2] = dz;
 }
 
@@ -1059,6 +1073,7 @@ struct DispatchParams {
     int32_t noise_w, noise_h;
     float light[3], cam[3], nos[4];
     uint32_t width, height, n;
+    uint32_t rank, world, tiles_x;   // world > 1: the buffers hold this rank's tiles (compact tile-major layout), n = local tiles * 1024
     float *out[4];             // org, shadowDir, reflectDir, ambientDir (any may be null)
 };
 
@@ -1080,8 +1095,8 @@ __global__ void __launch_bounds__(256) k_dispatch_rays(const DispatchParams p) {
     float o[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};   // NO_RAY: the targets' clear value (main.rs:157)
     if (tid < count) {
         const float4 nm = reinterpret_cast<const float4 *>(p.normal_mat)[i];
-        if (!(nm.w == MISS)) {                                       // :28 discard
-            const uint32_t px = i % p.width, py = i / p.width;
+        uint32_t px, py;
+        if (shard_pixel(i, p.width, p.height, p.rank, p.world, p.tiles_x, px, py) && !(nm.w == MISS)) {   // :28 discard
             const float fx = ((float)px + 0.5f) / (float)p.width, fy = ((float)py + 0.5f) / (float)p.height;   // quad01.vert:8 at the pixel centre
             const float x = sh_in[3 * tid], y = sh_in[3 * tid + 1], z = sh_in[3 * tid + 2];
             const V3 rnd = sample_albedo(p.noise, p.noise_w, p.noise_h, fx * p.nos[2] + p.nos[0], fy * p.nos[3] + p.nos[1]);   // :34

@@ -787,11 +787,17 @@ int rtamd_dispatch_rays_device(rtamd_context *ctx, const rtamd_dispatch_desc *d,
     if (!d->position || !d->normal_mat) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "position / normal_mat is NULL");
     if (((uintptr_t)d->position | (uintptr_t)d->normal_mat | (uintptr_t)o->org | (uintptr_t)o->shadow_dir | (uintptr_t)o->reflect_dir | (uintptr_t)o->ambient_dir) & 15u)
         return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "device buffers must be 16-byte aligned");
+    const uint32_t tile_world = d->tile_world ? d->tile_world : 1u;     // 0 (a zero-initialised descriptor) means the whole frame
+    if (d->tile_rank >= tile_world) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "tile_rank %u / tile_world %u invalid", d->tile_rank, d->tile_world);
+    uint32_t tiles_x = 0;
+    const uint32_t n_tiles = n_tiles_of(d->width, d->height, &tiles_x);
+    const uint64_t n_entries = tile_world == 1 ? (uint64_t)d->width * d->height : (uint64_t)local_tiles(n_tiles, d->tile_rank, tile_world) * RTAMD_TILE_PIXELS;
+    if (n_entries == 0) return RTAMD_OK;
     DeviceScope dev_scope;
     int rc = dev_scope.enter(ctx);
     if (rc) return rc;
     {
-        const uint64_t n = (uint64_t)d->width * d->height;
+        const uint64_t n = n_entries;
         if ((rc = check_range(ctx, d->position, n * 12, "position")) || (rc = check_range(ctx, d->normal_mat, n * 16, "normal_mat")) ||
             (rc = check_range(ctx, o->org, n * 12, "org")) || (rc = check_range(ctx, o->shadow_dir, n * 12, "shadow_dir")) ||
             (rc = check_range(ctx, o->reflect_dir, n * 12, "reflect_dir")) || (rc = check_range(ctx, o->ambient_dir, n * 12, "ambient_dir")))
@@ -803,7 +809,8 @@ int rtamd_dispatch_rays_device(rtamd_context *ctx, const rtamd_dispatch_desc *d,
     std::memcpy(p.light, d->light_pos, sizeof p.light);
     std::memcpy(p.cam, d->camera_pos, sizeof p.cam);
     std::memcpy(p.nos, d->noise_offset_scale, sizeof p.nos);
-    p.width = d->width; p.height = d->height; p.n = d->width * d->height;
+    p.width = d->width; p.height = d->height; p.n = (uint32_t)n_entries;
+    p.rank = d->tile_rank; p.world = tile_world; p.tiles_x = tiles_x;
     p.out[0] = o->org; p.out[1] = o->shadow_dir; p.out[2] = o->reflect_dir; p.out[3] = o->ambient_dir;
     hipLaunchKernelGGL(k_dispatch_rays, dim3((p.n + 255u) / 256u), dim3(256), 0, ctx->stream, p);
     HIP_TRY(ctx, hipGetLastError());
@@ -821,6 +828,7 @@ int rtamd_dispatch_rays(rtamd_context *ctx, const rtamd_dispatch_desc *d, const 
     DevBuf d_pos, d_nm, d_out[4];
     float *host_out[4] = {o->org, o->shadow_dir, o->reflect_dir, o->ambient_dir};
     rtamd_dispatch_desc dd = *d;
+    dd.tile_rank = 0; dd.tile_world = 1;      // the host-buffer form takes whole frames
     rtamd_dispatch_out od{};
     float **dev_out[4] = {&od.org, &od.shadow_dir, &od.reflect_dir, &od.ambient_dir};
     rc = RTAMD_OK;
@@ -1056,21 +1064,32 @@ int rtamd_trace(rtamd_context *ctx, uint64_t n, const float *org, const float *d
 
 int rtamd_generate_rays_offset_device(rtamd_context *ctx, uint32_t width, uint32_t height, const float inv_proj_view[16],
                                       float near_plane, float far_plane, float offset_x, float offset_y, float *dir_out) {
+    return rtamd_generate_rays_tiles_device(ctx, width, height, inv_proj_view, near_plane, far_plane, offset_x, offset_y, 0, 1, dir_out);
+}
+
+int rtamd_generate_rays_tiles_device(rtamd_context *ctx, uint32_t width, uint32_t height, const float inv_proj_view[16],
+                                     float near_plane, float far_plane, float offset_x, float offset_y,
+                                     uint32_t tile_rank, uint32_t tile_world, float *dir_out) {
     if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
     if (!inv_proj_view || !dir_out || width == 0 || height == 0) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "bad generate_rays arguments");
     if ((uint64_t)width * height > 0x7FFFFFFFull) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "frame too large");
     if (!(offset_x >= 0.0f && offset_x <= 1.0f && offset_y >= 0.0f && offset_y <= 1.0f)) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "sample offset must lie in [0,1]^2");
+    if (tile_world == 0 || tile_rank >= tile_world) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "tile_rank %u / tile_world %u invalid", tile_rank, tile_world);
+    uint32_t tiles_x = 0;
+    const uint32_t n_tiles = n_tiles_of(width, height, &tiles_x);
+    const uint64_t n_entries = tile_world == 1 ? (uint64_t)width * height : (uint64_t)local_tiles(n_tiles, tile_rank, tile_world) * RTAMD_TILE_PIXELS;
+    if (n_entries == 0) return RTAMD_OK;
     DeviceScope dev_scope;
     int rc = dev_scope.enter(ctx);
     if (rc) return rc;
-    if ((rc = check_range(ctx, dir_out, (uint64_t)width * height * 12, "dir_out"))) return rc;
+    if ((rc = check_range(ctx, dir_out, n_entries * 12, "dir_out"))) return rc;
     // the matrix travels in the kernel arguments: nothing of the caller's memory is read after return, and the call
     // does not wait for the stream (round 1 staged it through one device buffer and had to synchronise per call)
     Mat4Arg ipv;
     std::memcpy(ipv.m, inv_proj_view, sizeof ipv.m);
-    uint32_t n = width * height;
+    const uint32_t n = (uint32_t)n_entries;
     hipLaunchKernelGGL(k_generate_rays, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ipv, near_plane, far_plane, width, height,
-                       offset_x, offset_y, dir_out);
+                       offset_x, offset_y, tile_rank, tile_world, tiles_x, n, dir_out);
     HIP_TRY(ctx, hipGetLastError());
     return RTAMD_OK;
 }

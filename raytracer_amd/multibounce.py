@@ -5,7 +5,7 @@ three ray_trace.frag passes.  Here the same two shaders' restatements repeat, wi
 rtamd_surface_from_hits_device turning a bounce's hit records into the next G-buffer (the reference
 fills it with its rasteriser, src/main.rs:127-140).  Per sample s of a pixel:
 
-    jittered primary  rtamd_generate_rays_offset_device (R2 sequence; sample 0 = the pixel centre)
+    jittered primary  rtamd_generate_rays_tiles_device  (R2 sequence; sample 0 = the pixel centre)
     closest hit       rtamd_trace_device                           (ray_trace.frag:131-143)
     for depth 1..D:
         surface       rtamd_surface_from_hits_device               (position, normal | material)
@@ -54,16 +54,29 @@ class Lane:
 
 
 class MultiBounce:
-    def __init__(self, tracer, width, height, inv_proj_view, cam_pos, light_pos, has_normals, depth=3, lanes=4, device=0, noise_size=512):
+    def __init__(self, tracer, width, height, inv_proj_view, cam_pos, light_pos, has_normals, depth=3, lanes=4, device=0, noise_size=512,
+                 tile_rank=0, tile_world=1):
+        """tile_world > 1: this object traces one rank's interleaved 32 x 32 tiles of the frame (scene replicated, every sample
+        of a pixel on the GPU that owns its tile, no exchange between ranks); every buffer then holds local tiles * 1024
+        entries in the compact tile-major layout of include/rtamd.h, bit for bit the whole-frame chain's values of those pixels."""
         import torch
+        from .renderer import TILE_PIXELS
         self.torch = torch
-        self.tr, self.W, self.H, self.n = tracer, int(width), int(height), int(width) * int(height)
+        self.tr, self.W, self.H = tracer, int(width), int(height)
+        self.rank, self.world = int(tile_rank), int(tile_world)
+        self.n = self.W * self.H if self.world == 1 else tracer.local_tile_count(self.W, self.H, self.rank, self.world) * TILE_PIXELS
         self.inv = np.asarray(inv_proj_view, np.float32).reshape(16)
         self.cam = tuple(float(x) for x in cam_pos)
         self.light = tuple(float(x) for x in light_pos)
         self.has_n, self.depth, self.noise_size = int(bool(has_normals)), int(depth), int(noise_size)
         dev = torch.device("cuda", device)
         self.lanes = [Lane(torch, dev, self.n, self.cam) for _ in range(max(1, min(8, lanes)))]
+        # primaries actually traced: the shard's pixels inside the frame (entries of edge tiles outside it are NO_RAY)
+        tiles_x = (self.W + 31) // 32
+        g = np.arange(self.n // TILE_PIXELS if self.world > 1 else 0, dtype=np.int64) * self.world + self.rank
+        tw = np.minimum(32, self.W - (g % tiles_x) * 32)
+        th = np.minimum(32, self.H - (g // tiles_x) * 32)
+        self.n_primary = int((tw * th).sum()) if self.world > 1 else self.n
 
     def sample(self, s, lane=None, record=None):
         """Enqueue sample s on a lane's stream.  record: a dict that receives a device clone of every stage buffer,
@@ -79,9 +92,9 @@ class MultiBounce:
         with torch.cuda.stream(lane.stream):
             tr.set_stream(lane.stream.cuda_stream)
             ox, oy = sample_offset(s)
-            tr.generate_rays_offset_device(W, H, self.inv, ox, oy, lane.dir.data_ptr())
+            tr.generate_rays_tiles_device(W, H, self.inv, ox, oy, self.rank, self.world, lane.dir.data_ptr())
             tr.trace_device(n, lane.cam_org.data_ptr(), lane.dir.data_ptr(), lane.hits.data_ptr())
-            lane.rays += n
+            lane.rays += self.n_primary
             rec(0, dir=lane.dir, hits=lane.hits)
             org, d = lane.cam_org, lane.dir
             for depth in range(1, self.depth + 1):
@@ -89,7 +102,8 @@ class MultiBounce:
                 nos = noise_offset_scale(s, depth, W, H, self.noise_size)
                 t = lane.targets[depth & 1]
                 tr.dispatch_rays_device(W, H, lane.pos.data_ptr(), lane.nm.data_ptr(), self.light, self.cam, nos, org_ptr=t["org"].data_ptr(),
-                                        shadow_dir_ptr=t["shadow"].data_ptr(), reflect_dir_ptr=t["reflect"].data_ptr(), ambient_dir_ptr=t["ambient"].data_ptr())
+                                        shadow_dir_ptr=t["shadow"].data_ptr(), reflect_dir_ptr=t["reflect"].data_ptr(), ambient_dir_ptr=t["ambient"].data_ptr(),
+                                        tile_rank=self.rank, tile_world=self.world)
                 surfaces = (lane.nm[:, 3] != 1e30).sum()
                 tr.trace_device(n, t["org"].data_ptr(), t["shadow"].data_ptr(), lane.shadow_hits.data_ptr())
                 lane.rays += surfaces

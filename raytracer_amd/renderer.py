@@ -238,6 +238,12 @@ class HipRayTracer:
         self._check(self._lib.rtamd_generate_rays_offset_device(self._h, width, height, inv.ctypes.data_as(_ffi.c_float_p), NEAR, FAR,
                                                                 float(offset_x), float(offset_y), ctypes.c_void_p(dir_ptr)))
 
+    def generate_rays_tiles_device(self, width, height, inv_proj_view, offset_x, offset_y, tile_rank, tile_world, dir_ptr):
+        """rtamd_generate_rays_tiles_device: the rays of one rank's tile shard, compact tile-major layout."""
+        inv = np.ascontiguousarray(inv_proj_view, dtype=np.float32).reshape(16)
+        self._check(self._lib.rtamd_generate_rays_tiles_device(self._h, width, height, inv.ctypes.data_as(_ffi.c_float_p), NEAR, FAR,
+                                                               float(offset_x), float(offset_y), int(tile_rank), int(tile_world), ctypes.c_void_p(dir_ptr)))
+
     # ---- hit records -> G-buffer ---------------------------------------------
     def surface_from_hits(self, org, dir, hits, has_normals=False):
         o = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
@@ -259,9 +265,10 @@ class HipRayTracer:
             raise ValueError("noise texture must be (h, w, 3) uint8")
         self._check(self._lib.rtamd_upload_noise_texture(self._h, _ptr(t), t.shape[1], t.shape[0]))
 
-    def _dispatch_desc(self, width, height, position_ptr, normal_mat_ptr, light_pos, camera_pos, noise_offset_scale):
+    def _dispatch_desc(self, width, height, position_ptr, normal_mat_ptr, light_pos, camera_pos, noise_offset_scale, tile_rank=0, tile_world=1):
         d = _ffi.DispatchDesc()
         d.width, d.height = width, height
+        d.tile_rank, d.tile_world = int(tile_rank), int(tile_world)
         d.position, d.normal_mat = position_ptr, normal_mat_ptr
         d.light_pos[:] = [float(x) for x in light_pos]
         d.camera_pos[:] = [float(x) for x in camera_pos]
@@ -282,8 +289,8 @@ class HipRayTracer:
         return outs
 
     def dispatch_rays_device(self, width, height, position_ptr, normal_mat_ptr, light_pos, camera_pos, noise_offset_scale,
-                             org_ptr=0, shadow_dir_ptr=0, reflect_dir_ptr=0, ambient_dir_ptr=0):
-        d = self._dispatch_desc(width, height, position_ptr, normal_mat_ptr, light_pos, camera_pos, noise_offset_scale)
+                             org_ptr=0, shadow_dir_ptr=0, reflect_dir_ptr=0, ambient_dir_ptr=0, tile_rank=0, tile_world=1):
+        d = self._dispatch_desc(width, height, position_ptr, normal_mat_ptr, light_pos, camera_pos, noise_offset_scale, tile_rank, tile_world)
         o = _ffi.DispatchOut(org_ptr or None, shadow_dir_ptr or None, reflect_dir_ptr or None, ambient_dir_ptr or None)
         self._check(self._lib.rtamd_dispatch_rays_device(self._h, ctypes.byref(d), ctypes.byref(o)))
 

@@ -86,3 +86,24 @@ def test_rccl_calls_of_the_multi_gpu_path_on_one_rank():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, "-c", _RCCL_CHILD, REPO], cwd=REPO, env=env, capture_output=True, text=True, timeout=280)
     assert p.returncode == 0 and "RCCL_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+
+
+@pytest.mark.timeout(600)
+def test_c5_bench_two_rank_rehearsal_traces_the_single_gpu_ray_count():
+    """tools/bench_c5.py --gpus 2 (BASELINE config 5, tile-split) as two fresh rank processes on one GPU over gloo: the ranks'
+    shards together trace exactly the rays the single-process run traces (the chain's buffers are compared bit for bit in
+    tests/test_gpu_multibounce.py::test_tile_sharded_chain_equals_the_whole_frame_chain)."""
+    common = ["--spp", "3", "--width", "496", "--height", "270", "--lanes", "2"]
+    one = subprocess.run([sys.executable, os.path.join(REPO, "tools", "bench_c5.py"), *common], cwd=REPO, capture_output=True, text=True, timeout=280)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    env = dict(os.environ, RTAMD_BENCH_REHEARSE="1", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "tools", "bench_c5.py"), "--gpus", "2", *common]
+    two = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=280)
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["config"]["parallelism"] == "tiles2" and "REHEARSAL_not_a_measurement" in b
+    assert b["config"]["rays"] == a["config"]["rays"] > 3 * 496 * 270 * 2

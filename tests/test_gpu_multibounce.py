@@ -165,3 +165,62 @@ def test_multibounce_full_size_4k_properties(tracer, oracle_a, atrium_scene):
             d = r["ambient_dir"].reshape(n, 3)[idx]
             hits = sub((depth, "cont_hits"))
             assert np.array_equal(bits(hits), bits(oracle_a.trace(sc, org, d, nthreads=16)["hits"])), depth
+
+
+def _shard_index(w, h, rank, world):
+    """For every entry of rank's compact tile-major buffer: the scan-line index of its pixel, or -1 outside the frame."""
+    tiles_x, tiles_y = (w + 31) // 32, (h + 31) // 32
+    local = [g for g in range(tiles_x * tiles_y) if g % world == rank]
+    idx = np.full((len(local), 32, 32), -1, np.int64)
+    for j, g in enumerate(local):
+        tx, ty = g % tiles_x, g // tiles_x
+        ys, xs = np.mgrid[0:32, 0:32]
+        x, y = tx * 32 + xs, ty * 32 + ys
+        inside = (x < w) & (y < h)
+        idx[j][inside] = (y * w + x)[inside]
+    return idx.reshape(-1)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_sharded_chain_equals_the_whole_frame_chain(tracer, atrium_scene, world):
+    """BASELINE config 5 split over GPUs: every rank traces its interleaved 32 x 32 tiles of the frame through the same chain
+    (rtamd_generate_rays_tiles_device, the dispatcher's tile mode, ray lists for everything else).  Every buffer of every rank's
+    chain equals the whole-frame chain's — which test_multibounce_chain_equals_oracle_buffer_for_buffer pins to the oracle —
+    at the pixels of its tiles, bit for bit; entries of edge tiles outside the 240 x 135 frame are NO_RAY / cleared."""
+    sc, cam, noise = atrium_scene
+    w, h = 240, 135
+    camera = _camera(cam, w, h)
+    inv = np.asarray(camera.inv_proj_view(), np.float32).reshape(16)
+    tracer.upload_scene(sc)
+    tracer.upload_noise_texture(noise)
+    clear = {"hits": np.float32([1e30, 0, 0, 0]), "shadow_hits": np.float32([1e30, 0, 0, 0]), "cont_hits": np.float32([1e30, 0, 0, 0]),
+             "normal_mat": np.float32([0, 0, 0, 1e30])}
+    try:
+        whole = MultiBounce(tracer, w, h, inv, camera.position, LIGHT, True, depth=DEPTH, lanes=1)
+        total_rays = 0
+        for s in (1, 2):                                           # an odd and an even sample: both continuation kinds, off-centre offsets
+            full = {}
+            whole.sample(s, record=full)
+            whole.synchronize()
+            full = {k: v.cpu().numpy() for k, v in full.items()}
+            seen = np.zeros(w * h, np.int32)
+            for rank in range(world):
+                mb = MultiBounce(tracer, w, h, inv, camera.position, LIGHT, True, depth=DEPTH, lanes=1, tile_rank=rank, tile_world=world)
+                rec = {}
+                mb.sample(s, record=rec)
+                mb.synchronize()
+                idx = _shard_index(w, h, rank, world)
+                inside = idx >= 0
+                assert mb.n == len(idx) and mb.n_primary == int(inside.sum())
+                seen[idx[inside]] += 1
+                assert set(rec) == set(full)
+                for key in sorted(full):
+                    got = rec[key].cpu().numpy()
+                    assert np.array_equal(bits(got[inside]), bits(full[key][idx[inside]])), (s, rank, key)
+                    want_out = clear.get(key[1], np.zeros(got.shape[1], np.float32))
+                    assert np.array_equal(bits(got[~inside]), bits(np.broadcast_to(want_out, got[~inside].shape))), (s, rank, key, "outside the frame")
+                total_rays += mb.rays_traced()
+            assert np.all(seen == 1)                                # the ranks' tiles partition the frame
+        assert total_rays == whole.rays_traced()                   # the shards trace the whole frame's rays, no more
+    finally:
+        tracer.set_stream(0)

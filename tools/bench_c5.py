@@ -3,7 +3,12 @@
 Sponza-class atrium, 3840x2160, S samples per pixel, depth <= 3, through raytracer_amd/multibounce.py (the chain
 tests/test_gpu_multibounce.py checks buffer by buffer against the oracle).  Samples rotate over --lanes streams
 with their own buffers.  A ray = one traversal that was actually started (NO_RAY entries are not counted).
-Usage: tools/bench_c5.py [--spp 8] [--width 3840 --height 2160] [--depth 3]"""
+Several GPUs (`python -m torch.distributed.run --nproc-per-node N tools/bench_c5.py --gpus N`): every rank traces its
+interleaved 32x32 tiles of the frame (scene replicated, all samples of a pixel on the GPU that owns its tile, no
+collective in the chain: there is no frame to assemble, the records ARE the output); barrier + synchronise on both sides of
+the timed region, time = MAX over ranks, rays = SUM.  RTAMD_BENCH_REHEARSE=1 puts every rank on cuda:0 over gloo (a code-path
+rehearsal on a one-GPU box, not a measurement).
+Usage: tools/bench_c5.py [--spp 8] [--width 3840 --height 2160] [--depth 3] [--gpus N]"""
 import argparse, json, os, sys, time
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,30 +23,60 @@ ap.add_argument("--spp", type=int, default=8)
 ap.add_argument("--width", type=int, default=3840)
 ap.add_argument("--height", type=int, default=2160)
 ap.add_argument("--depth", type=int, default=3)
+ap.add_argument("--gpus", type=int, default=1)
 ap.add_argument("--lanes", type=int, default=4, help="samples in flight (streams); measured 1 / 2 / 3 / 4 / 6: 6.21 / 6.71 / 6.44 / 6.92 / 6.22 Grays/s (4 = one per default hardware queue)")
 args = ap.parse_args()
 W, H, n = args.width, args.height, args.width * args.height
+world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+if world != args.gpus and world > 1:
+    raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+rehearse = world > 1 and os.environ.get("RTAMD_BENCH_REHEARSE") == "1"
+if rehearse:
+    local_rank = 0
+torch.cuda.set_device(local_rank)
+if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group("gloo") if rehearse else dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 model, camera, _, _, tex = bench.build_workload("atrium_1080p")
 camera.aspect = W / H
 sc = model.scene_arrays()
-tr = HipRayTracer(0)
+tr = HipRayTracer(local_rank)
 tr.upload_scene(sc)
 rng = np.random.default_rng(3)
 v = rng.normal(size=(512, 512, 3)); v /= np.linalg.norm(v, axis=-1, keepdims=True)
 tr.upload_noise_texture(np.clip(np.round((v * 0.5 + 0.5) * 255), 0, 255).astype(np.uint8))
-mb = MultiBounce(tr, W, H, camera.inv_proj_view(), camera.position, (0.0, 12.0, 0.0), model.has_normals(), depth=args.depth, lanes=args.lanes)
+mb = MultiBounce(tr, W, H, camera.inv_proj_view(), camera.position, (0.0, 12.0, 0.0), model.has_normals(), depth=args.depth, lanes=args.lanes,
+                 device=local_rank, tile_rank=rank, tile_world=world)
 for s in range(len(mb.lanes)):
     mb.sample(s)
 mb.rays_traced(reset=True)
 torch.cuda.synchronize()
+if world > 1:
+    dist.barrier()
+    torch.cuda.synchronize()
 t0 = time.perf_counter()
 for s in range(args.spp):
     mb.sample(s)
 torch.cuda.synchronize()
+if world > 1:
+    dist.barrier()
+    torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 rays = mb.rays_traced()
-print(json.dumps({"metric": "Mrays/s", "value": round(rays / dt / 1e6, 1), "unit": "Mrays/s", "n_gpus": 1,
+if world > 1:
+    dev = torch.device("cpu") if rehearse else torch.device("cuda", local_rank)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    r = torch.tensor([rays], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(r)
+    dt, rays = float(t[0]), int(r[0])
+    dist.destroy_process_group()
+    if rank != 0:
+        sys.exit(0)
+print(json.dumps({"metric": "Mrays/s", "value": round(rays / dt / 1e6, 1), "unit": "Mrays/s", "n_gpus": world, "scaling": "strong",
+                  **({"REHEARSAL_not_a_measurement": "all ranks on cuda:0, gloo"} if rehearse else {}),
                   "config": {"workload": f"C5: atrium {len(sc['triangles'])} triangles, {W}x{H}, {args.spp} spp, depth <= {args.depth}, "
                                          "primary + (shadow + mirror|ambient continuation) per bounce", "rays": rays,
-                             "rays_per_pixel_sample": round(rays / (n * args.spp), 3), "samples_in_flight": len(mb.lanes)},
+                             "rays_per_pixel_sample": round(rays / (n * args.spp), 3), "samples_in_flight": len(mb.lanes),
+                             "parallelism": f"tiles{world}" if world > 1 else "single"},
                   "seconds": round(dt, 4), "ms_per_sample_frame": round(dt / args.spp * 1e3, 3), "data": "synthetic", "dtype": "f32"}))
