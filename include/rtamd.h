@@ -238,6 +238,21 @@ int rtamd_render_device_static(rtamd_context *ctx, const rtamd_frame_desc *desc,
 int rtamd_trace(rtamd_context *ctx, uint64_t n, const float *org, const float *dir, float *hits);
 int rtamd_trace_device(rtamd_context *ctx, uint64_t n, const float *org, const float *dir, float *hits);
 
+/* Several ray lists in ONE launch: the persistent kernel pulls the work items of all n_jobs lists from one queue, so the
+ * slow tail of a list (its last, most expensive rays, during which most of the GPU idles) runs beside the next list's rays —
+ * what rtamd_render_batch_device does for frames.  The reference draws its three ray_trace passes one after the other
+ * (src/main.rs:176-203: shadow, reflection, ambient rays of one dispatcher pass); they are independent, and so are the
+ * passes of different samples of a multi-sample frame: hand them over together.  Job j's records are bit for bit those
+ * of rtamd_trace_device(jobs[j]).  Limits: 1..RTAMD_MAX_BATCH_FRAMES lists, fewer than 2^28 rays per list when
+ * n_jobs > 1; a list may be empty.  Device pointers; enqueues on the context's stream and returns. */
+typedef struct rtamd_trace_job {
+    uint64_t n;           /* rays in this list */
+    const float *org;     /* 3 floats per ray */
+    const float *dir;     /* 3 floats per ray; (0,0,0) = NO_RAY */
+    float *hits;          /* 4 floats per ray: (t, u, v, bits(triangle index)) */
+} rtamd_trace_job;
+int rtamd_trace_batch_device(rtamd_context *ctx, uint32_t n_jobs, const rtamd_trace_job *jobs);
+
 /* ---- ray generation: ray_trace/ray_create.frag:12 + util/quad-11.vert:8 ---- */
 
 /* dir_out: 3 floats per pixel, scan-line order, row 0 = bottom row. */

@@ -73,6 +73,10 @@ class DispatchDesc(ctypes.Structure):
     ]
 
 
+class TraceJob(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_uint64), ("org", ctypes.c_void_p), ("dir", ctypes.c_void_p), ("hits", ctypes.c_void_p)]
+
+
 class DispatchOut(ctypes.Structure):
     _fields_ = [("org", ctypes.c_void_p), ("shadow_dir", ctypes.c_void_p), ("reflect_dir", ctypes.c_void_p), ("ambient_dir", ctypes.c_void_p)]
 
@@ -184,6 +188,8 @@ def device_lib():
         for name in ("rtamd_trace", "rtamd_trace_device"):
             getattr(L, name).argtypes = [vp, ctypes.c_uint64, vp, vp, vp]
             getattr(L, name).restype = ctypes.c_int
+        L.rtamd_trace_batch_device.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(TraceJob)]
+        L.rtamd_trace_batch_device.restype = ctypes.c_int
         for name in ("rtamd_generate_rays", "rtamd_generate_rays_device"):
             getattr(L, name).argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, c_float_p, ctypes.c_float, ctypes.c_float, vp]
             getattr(L, name).restype = ctypes.c_int

@@ -93,7 +93,7 @@ struct FrameIO {
     float ipv[16];
     float near_, far_;
     float cam[3];
-    uint32_t pad;
+    uint32_t n_rays;              // trace batch: rays of this job (dir / org = its ray list, rgba = its hit records); else 0
 };
 static_assert(sizeof(FrameIO) == 136, "FrameIO layout");
 static_assert(MAX_BATCH_FRAMES <= (1 << (32 - BATCH_FRAME_SHIFT)), "the frame index must fit above BATCH_FRAME_SHIFT");
@@ -134,8 +134,11 @@ struct JobParams {
     uint32_t spill_wave_words;    // u32 words per wave slot of `spill` (SPILL_STACK_ENTRIES * 64 for the context's own areas)
     // batch of frames in ONE launch (k_persistent, fused mode): item i belongs to frame i / items_per_frame; frame f's rays,
     // camera and outputs are frames[f] (the fields above are not used then).  n_frames == 1: the fields above, as ever.
+    // batch of ray lists in ONE launch (trace mode): job j owns items job_item_begin[j] .. job_item_begin[j + 1] - 1; its ray list
+    // and hit records are frames[j].{org, dir, rgba}, its length frames[j].n_rays (< 2^28: a lane carries the job like a frame)
     uint32_t n_frames;
     uint32_t items_per_frame;
+    uint32_t job_item_begin[MAX_BATCH_FRAMES + 1];
     FrameIO frames[MAX_BATCH_FRAMES];
 #ifdef RTAMD_EXP_STAMPS
     unsigned long long *stamps;   // diagnostic build only: per wave {start, end, items, xcc} in 100 MHz ticks
@@ -664,8 +667,13 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
     // fused shader: the in-shadow colour of a lane's pixel waits here ([channel][thread]) while its shadow ray is traced
     __shared__ float lds_shadow_col[MODE == MODE_FUSED ? 3 * BLOCK : 1];
     // batch of frames: a lane finds its frame's output buffers here (filled from the kernel arguments below)
-    __shared__ uint64_t lds_frame_out[MODE == MODE_FUSED ? MAX_BATCH_FRAMES : 1][4];
+    __shared__ uint64_t lds_frame_out[MAX_BATCH_FRAMES][MODE == MODE_FUSED ? 4 : 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (MODE == MODE_TRACE && p.n_frames > 1u) {
+        for (uint32_t f = 0; f < p.n_frames; f++)
+            if (tid == f) lds_frame_out[f][0] = (uint64_t)(uintptr_t)p.frames[f].rgba;     // the job's hit records
+        __syncthreads();
+    }
     if (MODE == MODE_FUSED && p.n_frames > 1u) {
         for (uint32_t f = 0; f < p.n_frames; f++)      // f is wave-uniform: scalar loads of the arguments, one lane stores
             if (tid == f) {
@@ -778,14 +786,24 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                         phase = PH_PRIMARY | ray_pos_flag(tr.ray);
                     }
                 } else {
-                    const uint64_t ri = (uint64_t)pool_item * 64u + l;
-                    if (ri < p.n_rays) {
-                        const float *d = p.dir + 3 * ri, *o = p.org + 3 * ri;
-                        out_index = (uint32_t)ri;
+                    // batch of ray lists: item -> (job, item of that job); everything here is wave-uniform
+                    uint32_t job = 0, item_in_job = pool_item;
+                    const float *j_dir = p.dir, *j_org = p.org;
+                    float *j_hits = p.hits;
+                    uint64_t j_rays = p.n_rays;
+                    if (p.n_frames > 1u) {
+                        for (uint32_t k = 1; k < p.n_frames; k++) if (pool_item >= p.job_item_begin[k]) job = k;
+                        item_in_job = pool_item - p.job_item_begin[job];
+                        j_dir = p.frames[job].dir; j_org = p.frames[job].org; j_hits = p.frames[job].rgba; j_rays = p.frames[job].n_rays;
+                    }
+                    const uint64_t ri = (uint64_t)item_in_job * 64u + l;
+                    if (ri < j_rays) {
+                        const float *d = j_dir + 3 * ri, *o = j_org + 3 * ri;
+                        out_index = (uint32_t)ri | (job << BATCH_FRAME_SHIFT);      // job is 0 unless this is a batch
                         nbox = 0; ntri = 0;
                         if (d[0] == 0.0f && d[1] == 0.0f && d[2] == 0.0f) {
                             // NO_RAY: the fragment is discarded, the target keeps its clear value
-                            *reinterpret_cast<float4 *>(p.hits + 4 * ri) = make_float4(MISS, 0.0f, 0.0f, 0.0f);
+                            *reinterpret_cast<float4 *>(j_hits + 4 * ri) = make_float4(MISS, 0.0f, 0.0f, 0.0f);
                             if (COUNT && p.counts) { p.counts[2 * ri] = 0; p.counts[2 * ri + 1] = 0; }
                         } else {
                             set_ray(tr.ray, o[0], o[1], o[2], d[0], d[1], d[2]);
@@ -870,8 +888,14 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
         if (phase != PH_IDLE && tr.cur == REF_NONE) {
             if (MODE == MODE_TRACE) {
                 // ray_trace.frag:139-142
-                *reinterpret_cast<float4 *>(p.hits + 4 * (size_t)out_index) = make_float4(tr.t, tr.u, tr.v, __uint_as_float(tr.idx));
-                if (COUNT && p.counts) { p.counts[2 * (size_t)out_index] = nbox; p.counts[2 * (size_t)out_index + 1] = ntri; }
+                float *o_hits = p.hits;
+                uint32_t out_i = out_index;
+                if (p.n_frames > 1u) {      // batch: the lane's job sits above BATCH_FRAME_SHIFT, its hit records in the LDS table
+                    o_hits = (float *)(uintptr_t)lds_frame_out[out_index >> BATCH_FRAME_SHIFT][0];
+                    out_i = out_index & ((1u << BATCH_FRAME_SHIFT) - 1u);
+                }
+                *reinterpret_cast<float4 *>(o_hits + 4 * (size_t)out_i) = make_float4(tr.t, tr.u, tr.v, __uint_as_float(tr.idx));
+                if (COUNT && p.counts) { p.counts[2 * (size_t)out_i] = nbox; p.counts[2 * (size_t)out_i + 1] = ntri; }
                 phase = PH_IDLE;
             } else {
               // this lane's output buffers: the kernel arguments, or for a batch its frame's entry of the LDS table

@@ -1036,7 +1036,42 @@ int rtamd_trace_device(rtamd_context *ctx, uint64_t n, const float *org, const f
     p.dir = dir; p.org = org; p.hits = hits; p.n_rays = n;
     p.n_items = (uint32_t)((n + 63) / 64);
     p.world = 1;
+    p.n_frames = 1;
     return launch_main(ctx, MODE_TRACE, false, p);
+}
+
+int rtamd_trace_batch_device(rtamd_context *ctx, uint32_t n_jobs, const rtamd_trace_job *jobs) {
+    if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
+    if (!ctx->has_scene) return fail(ctx, RTAMD_ERR_NO_SCENE, "no scene uploaded");
+    if (n_jobs == 0 || n_jobs > RTAMD_MAX_BATCH_FRAMES) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "a batch holds 1..%d ray lists, not %u", RTAMD_MAX_BATCH_FRAMES, n_jobs);
+    if (!jobs) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "jobs is NULL");
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        if (jobs[j].n && (!jobs[j].org || !jobs[j].dir || !jobs[j].hits)) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "job %u: org / dir / hits is NULL", j);
+        if (jobs[j].n >= (1ull << BATCH_FRAME_SHIFT) && n_jobs > 1) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "job %u: the ray lists of a batch are limited to 2^%u - 1 rays", j, BATCH_FRAME_SHIFT);
+    }
+    int rc;
+    if (n_jobs == 1 || ctx->variant != 0) {      // the A/B baseline kernel has no batch form: list by list
+        for (uint32_t j = 0; j < n_jobs; j++) if ((rc = rtamd_trace_device(ctx, jobs[j].n, jobs[j].org, jobs[j].dir, jobs[j].hits))) return rc;
+        return RTAMD_OK;
+    }
+    DeviceScope dev_scope;
+    if ((rc = dev_scope.enter(ctx))) return rc;
+    JobParams p;
+    std::memset(&p, 0, sizeof p);
+    p.world = 1;
+    p.n_frames = n_jobs;
+    uint32_t items = 0;
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        const uint64_t n = jobs[j].n;
+        if ((rc = check_range(ctx, jobs[j].org, n * 12, "org")) || (rc = check_range(ctx, jobs[j].dir, n * 12, "dir")) || (rc = check_range(ctx, jobs[j].hits, n * 16, "hits"))) return rc;
+        p.job_item_begin[j] = items;
+        items += (uint32_t)((n + 63) / 64);          // <= 16 * 2^22 items
+        FrameIO &io = p.frames[j];
+        io.org = jobs[j].org; io.dir = jobs[j].dir; io.rgba = jobs[j].hits; io.n_rays = (uint32_t)n;
+    }
+    for (uint32_t j = n_jobs; j <= (uint32_t)MAX_BATCH_FRAMES; j++) p.job_item_begin[j] = items;
+    p.n_items = items;
+    return launch_main(ctx, MODE_TRACE, false, p);     // n_items == 0 (every list empty): nothing to launch
 }
 
 int rtamd_trace(rtamd_context *ctx, uint64_t n, const float *org, const float *dir, float *hits) {

@@ -70,7 +70,7 @@ class MultiBounce:
         self.light = tuple(float(x) for x in light_pos)
         self.has_n, self.depth, self.noise_size = int(bool(has_normals)), int(depth), int(noise_size)
         dev = torch.device("cuda", device)
-        self.lanes = [Lane(torch, dev, self.n, self.cam) for _ in range(max(1, min(8, lanes)))]
+        self.lanes = [Lane(torch, dev, self.n, self.cam) for _ in range(max(1, min(16, lanes)))]
         # primaries actually traced: the shard's pixels inside the frame (entries of edge tiles outside it are NO_RAY)
         tiles_x = (self.W + 31) // 32
         g = np.arange(self.n // TILE_PIXELS if self.world > 1 else 0, dtype=np.int64) * self.world + self.rank
@@ -117,6 +117,62 @@ class MultiBounce:
                     rec(depth, cont_hits=lane.hits)
                     org, d = t["org"], cont
         return lane
+
+    def sample_batch(self, samples, lanes=None, records=None):
+        """Several samples in lock step: sample samples[k] uses the buffers of lanes[k], everything is enqueued on lanes[0]'s
+        stream, and the traversals of one stage — all samples' primaries, then per bounce all shadow and continuation rays —
+        go out as ONE rtamd_trace_batch_device launch (up to 8 samples: 16 ray lists), so that the slow tail of a list runs
+        beside the other lists' rays instead of beside an idle GPU.  Same buffers, bit for bit, as sample() gives each sample.
+        records: a list of dicts (one per sample), filled like sample()'s record."""
+        torch, tr, n, W, H = self.torch, self.tr, self.n, self.W, self.H
+        lanes = list(lanes if lanes is not None else self.lanes[:len(samples)])
+        if not 1 <= len(samples) <= 8 or len(lanes) != len(samples):
+            raise ValueError("1..8 samples, one lane each")
+        K = len(samples)
+
+        def rec(k, depth, **bufs):
+            if records is not None:
+                for key, v in bufs.items():
+                    records[k][(depth, key)] = v.clone()
+
+        head = lanes[0]
+        with torch.cuda.stream(head.stream):
+            tr.set_stream(head.stream.cuda_stream)
+            for k, s in enumerate(samples):
+                ox, oy = sample_offset(s)
+                tr.generate_rays_tiles_device(W, H, self.inv, ox, oy, self.rank, self.world, lanes[k].dir.data_ptr())
+            tr.trace_batch_device([(n, ln.cam_org.data_ptr(), ln.dir.data_ptr(), ln.hits.data_ptr()) for ln in lanes])
+            head.rays += self.n_primary * K
+            for k, ln in enumerate(lanes):
+                rec(k, 0, dir=ln.dir, hits=ln.hits)
+            cur = [(ln.cam_org, ln.dir) for ln in lanes]
+            for depth in range(1, self.depth + 1):
+                jobs, surfaces = [], 0
+                for k, (s, ln) in enumerate(zip(samples, lanes)):
+                    org, d = cur[k]
+                    tr.surface_from_hits_device(n, org.data_ptr(), d.data_ptr(), ln.hits.data_ptr(), self.has_n, ln.pos.data_ptr(), ln.nm.data_ptr())
+                    t = ln.targets[depth & 1]
+                    tr.dispatch_rays_device(W, H, ln.pos.data_ptr(), ln.nm.data_ptr(), self.light, self.cam, noise_offset_scale(s, depth, W, H, self.noise_size),
+                                            org_ptr=t["org"].data_ptr(), shadow_dir_ptr=t["shadow"].data_ptr(), reflect_dir_ptr=t["reflect"].data_ptr(),
+                                            ambient_dir_ptr=t["ambient"].data_ptr(), tile_rank=self.rank, tile_world=self.world)
+                    n_surf = (ln.nm[:, 3] != 1e30).sum()
+                    surfaces = surfaces + n_surf * (2 if depth < self.depth else 1)
+                    jobs.append((n, t["org"].data_ptr(), t["shadow"].data_ptr(), ln.shadow_hits.data_ptr()))
+                    rec(k, depth, position=ln.pos, normal_mat=ln.nm)      # hits is overwritten by this stage's continuation trace
+                for k, (s, ln) in enumerate(zip(samples, lanes)):
+                    if depth < self.depth:
+                        t = ln.targets[depth & 1]
+                        cont = t["reflect"] if s % 2 == 0 else t["ambient"]
+                        jobs.append((n, t["org"].data_ptr(), cont.data_ptr(), ln.hits.data_ptr()))
+                        cur[k] = (t["org"], cont)
+                tr.trace_batch_device(jobs)
+                head.rays += surfaces
+                for k, ln in enumerate(lanes):
+                    t = ln.targets[depth & 1]
+                    rec(k, depth, org=t["org"], shadow_dir=t["shadow"], reflect_dir=t["reflect"], ambient_dir=t["ambient"], shadow_hits=ln.shadow_hits)
+                    if depth < self.depth:
+                        rec(k, depth, cont_hits=ln.hits)
+        return head
 
     def synchronize(self):
         for lane in self.lanes:

@@ -221,6 +221,11 @@ class HipRayTracer:
     def trace_device(self, n, org_ptr, dir_ptr, hits_ptr):
         self._check(self._lib.rtamd_trace_device(self._h, int(n), ctypes.c_void_p(org_ptr), ctypes.c_void_p(dir_ptr), ctypes.c_void_p(hits_ptr)))
 
+    def trace_batch_device(self, jobs):
+        """rtamd_trace_batch_device: up to 16 ray lists in one launch.  jobs: a sequence of (n, org_ptr, dir_ptr, hits_ptr)."""
+        arr = (_ffi.TraceJob * len(jobs))(*[_ffi.TraceJob(int(n), o or None, d or None, h or None) for n, o, d, h in jobs])
+        self._check(self._lib.rtamd_trace_batch_device(self._h, len(jobs), arr))
+
     # ---- ray generation / assembly -----------------------------------------
     def generate_rays(self, width, height, inv_proj_view):
         inv = np.ascontiguousarray(inv_proj_view, dtype=np.float32).reshape(16)

@@ -706,3 +706,53 @@ def test_device_buffers_are_range_checked(tracer):
         tracer.synchronize()
         for p in (rays, out, hits):
             assert hip.hipFree(ctypes.c_void_p(p)) == 0
+
+
+@pytest.mark.parametrize("dyn_thresh", [0, 32])
+def test_trace_batch_equals_list_by_list(tracer, dyn_thresh):
+    """rtamd_trace_batch_device: 16 ray lists of ragged lengths (empty, shorter than a work item, not multiples of 64, NO_RAY
+    entries) in one launch give, list by list, the bits of rtamd_trace_device; also with lane re-fill forced on, where the lanes
+    of one wave belong to different lists.  The A/B baseline kernel takes the list-by-list path of the same entry point."""
+    import torch
+    g = load_golden("bunny")
+    tracer.upload_scene(g["scene"])
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(17)
+    lengths = [0, 1, 63, 64, 65, 1000, 4096, 5, 777, 12345, 0, 2, 129, 3000, 64 * 50, 191]
+    lo, hi = g["scene"]["positions"].min(0), g["scene"]["positions"].max(0)
+    jobs, bufs = [], []
+    for k, n in enumerate(lengths):
+        org = ((lo + hi) / 2 + rng.uniform(-1.0, 1.0, (n, 3)) * (hi - lo)).astype(np.float32)
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        d[::7] = 0.0                                                     # NO_RAY
+        t_org, t_dir = torch.from_numpy(org).to(dev), torch.from_numpy(d).to(dev)
+        hits_b = torch.full((max(n, 1), 4), -3.0, dtype=torch.float32, device=dev)
+        hits_s = torch.full((max(n, 1), 4), -5.0, dtype=torch.float32, device=dev)
+        bufs.append((t_org, t_dir, hits_b, hits_s))
+        jobs.append((n, t_org.data_ptr() if n else 0, t_dir.data_ptr() if n else 0, hits_b.data_ptr() if n else 0))
+    tracer.set_option("dyn_thresh", dyn_thresh)
+    try:
+        for variant in (0, 1):
+            tracer.set_kernel_variant(variant)
+            for _, _, hb, _ in bufs:
+                hb.fill_(-3.0)
+            tracer.trace_batch_device(jobs)
+            for n, (t_org, t_dir, _, hits_s) in zip(lengths, bufs):
+                if n:
+                    tracer.trace_device(n, t_org.data_ptr(), t_dir.data_ptr(), hits_s.data_ptr())
+            tracer.synchronize()
+            n_hit = 0
+            for n, (_, _, hits_b, hits_s) in zip(lengths, bufs):
+                if n:
+                    assert torch.equal(hits_b.view(torch.int32), hits_s.view(torch.int32)), (variant, n)
+                    n_hit += int((hits_b[:, 0] < 1e30).sum())
+                else:
+                    assert bool((hits_b == -3.0).all())
+            assert n_hit > 1000
+        with pytest.raises(RtamdError):
+            tracer.trace_batch_device(jobs + [jobs[3]])                    # 17 lists
+        tracer.trace_batch_device([jobs[0], jobs[10]])                     # nothing but empty lists: a no-op
+        tracer.synchronize()
+    finally:
+        tracer.set_kernel_variant(0)
+        tracer.set_option("dyn_thresh", 0)

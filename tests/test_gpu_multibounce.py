@@ -224,3 +224,33 @@ def test_tile_sharded_chain_equals_the_whole_frame_chain(tracer, atrium_scene, w
         assert total_rays == whole.rays_traced()                   # the shards trace the whole frame's rays, no more
     finally:
         tracer.set_stream(0)
+
+
+def test_samples_in_lock_step_equal_samples_one_by_one(tracer, atrium_scene):
+    """MultiBounce.sample_batch: five samples whose traversals go out stage by stage as ONE rtamd_trace_batch_device launch (5
+    primaries; 10 shadow + continuation lists per bounce) leave, sample by sample, the buffers sample() leaves — also on a tile shard."""
+    import torch
+    sc, cam, noise = atrium_scene
+    w, h = 240, 135
+    camera = _camera(cam, w, h)
+    inv = np.asarray(camera.inv_proj_view(), np.float32).reshape(16)
+    tracer.upload_scene(sc)
+    tracer.upload_noise_texture(noise)
+    samples = [0, 1, 2, 5, 8]
+    try:
+        for rank, world in ((0, 1), (1, 3)):
+            mb = MultiBounce(tracer, w, h, inv, camera.position, LIGHT, True, depth=DEPTH, lanes=5, tile_rank=rank, tile_world=world)
+            recs = [{} for _ in samples]
+            mb.sample_batch(samples, records=recs)
+            mb.synchronize()
+            batch_rays = mb.rays_traced(reset=True)
+            for k, s in enumerate(samples):
+                one = {}
+                mb.sample(s, lane=mb.lanes[0], record=one)
+                mb.synchronize()
+                assert set(one) == set(recs[k]) and len(one) == 2 + DEPTH * 7 + (DEPTH - 1)
+                for key in one:
+                    assert torch.equal(one[key].view(torch.int32), recs[k][key].view(torch.int32)), (world, s, key)
+            assert mb.rays_traced() == batch_rays
+    finally:
+        tracer.set_stream(0)

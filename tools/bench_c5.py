@@ -24,6 +24,12 @@ ap.add_argument("--width", type=int, default=3840)
 ap.add_argument("--height", type=int, default=2160)
 ap.add_argument("--depth", type=int, default=3)
 ap.add_argument("--gpus", type=int, default=1)
+ap.add_argument("--batch", type=int, default=-1, help="samples in lock step per rtamd_trace_batch_device launch (1..8); 0: one sample per lane, "
+                                                      "a launch per traversal (MultiBounce.sample); -1 = auto: 0 for the whole frame on one GPU "
+                                                      "(measured equal: 6.95 vs 7.02 Grays/s), 8 for a tile share (a 1/8 share: 1.10 -> 0.87 ms per sample frame)")
+ap.add_argument("--groups", type=int, default=2, help="with --batch: batches in flight (streams)")
+ap.add_argument("--share-of", type=int, default=0, help="one process, one GPU: trace only rank 0's tile share of a split over that many ranks "
+                                                         "(what one rank of an N-GPU run has to do; for scaling expectations)")
 ap.add_argument("--lanes", type=int, default=4, help="samples in flight (streams); measured 1 / 2 / 3 / 4 / 6: 6.21 / 6.71 / 6.44 / 6.92 / 6.22 Grays/s (4 = one per default hardware queue)")
 args = ap.parse_args()
 W, H, n = args.width, args.height, args.width * args.height
@@ -37,6 +43,12 @@ torch.cuda.set_device(local_rank)
 if world > 1:
     import torch.distributed as dist
     dist.init_process_group("gloo") if rehearse else dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+if args.share_of > 1 and world == 1:
+    world_for_tiles, rank_for_tiles = args.share_of, 0
+else:
+    world_for_tiles, rank_for_tiles = world, rank
+if args.batch < 0:
+    args.batch = 8 if world_for_tiles > 1 else 0
 model, camera, _, _, tex = bench.build_workload("atrium_1080p")
 camera.aspect = W / H
 sc = model.scene_arrays()
@@ -45,18 +57,29 @@ tr.upload_scene(sc)
 rng = np.random.default_rng(3)
 v = rng.normal(size=(512, 512, 3)); v /= np.linalg.norm(v, axis=-1, keepdims=True)
 tr.upload_noise_texture(np.clip(np.round((v * 0.5 + 0.5) * 255), 0, 255).astype(np.uint8))
-mb = MultiBounce(tr, W, H, camera.inv_proj_view(), camera.position, (0.0, 12.0, 0.0), model.has_normals(), depth=args.depth, lanes=args.lanes,
-                 device=local_rank, tile_rank=rank, tile_world=world)
-for s in range(len(mb.lanes)):
-    mb.sample(s)
+mb = MultiBounce(tr, W, H, camera.inv_proj_view(), camera.position, (0.0, 12.0, 0.0), model.has_normals(), depth=args.depth, lanes=(args.batch * args.groups if args.batch else args.lanes),
+                 device=local_rank, tile_rank=rank_for_tiles, tile_world=world_for_tiles)
+def run(spp):
+    if not args.batch:
+        for s in range(spp):
+            mb.sample(s)
+        return
+    K, b = args.batch, 0
+    for s0 in range(0, spp, K):
+        ss = list(range(s0, min(spp, s0 + K)))
+        g = b % args.groups
+        mb.sample_batch(ss, lanes=mb.lanes[g * K: g * K + len(ss)])
+        b += 1
+
+
+run(len(mb.lanes))
 mb.rays_traced(reset=True)
 torch.cuda.synchronize()
 if world > 1:
     dist.barrier()
     torch.cuda.synchronize()
 t0 = time.perf_counter()
-for s in range(args.spp):
-    mb.sample(s)
+run(args.spp)
 torch.cuda.synchronize()
 if world > 1:
     dist.barrier()
@@ -77,6 +100,6 @@ print(json.dumps({"metric": "Mrays/s", "value": round(rays / dt / 1e6, 1), "unit
                   **({"REHEARSAL_not_a_measurement": "all ranks on cuda:0, gloo"} if rehearse else {}),
                   "config": {"workload": f"C5: atrium {len(sc['triangles'])} triangles, {W}x{H}, {args.spp} spp, depth <= {args.depth}, "
                                          "primary + (shadow + mirror|ambient continuation) per bounce", "rays": rays,
-                             "rays_per_pixel_sample": round(rays / (n * args.spp), 3), "samples_in_flight": len(mb.lanes),
-                             "parallelism": f"tiles{world}" if world > 1 else "single"},
+                             "rays_per_pixel_sample": round(rays / (n * args.spp), 3), "samples_in_flight": len(mb.lanes), "samples_per_trace_launch": args.batch or 1,
+                             "parallelism": f"tiles{world}" if world > 1 else (f"rank 0's share of tiles{args.share_of}, alone on one GPU" if args.share_of > 1 else "single")},
                   "seconds": round(dt, 4), "ms_per_sample_frame": round(dt / args.spp * 1e3, 3), "data": "synthetic", "dtype": "f32"}))
