@@ -114,6 +114,33 @@ int main() {
         CHECK(rtamd_display_rgba8_device(ctx, d_rgba, n + 1, d8) == RTAMD_ERR_INVALID_ARGUMENT);
         CHECK(hipDeviceSynchronize() == hipSuccess); (void)hipFree(d8);
     }
+    // round 2, later: ray lists in one launch, tile shards of ray generation and of the dispatcher
+    {
+        const uint32_t tiles = rtamd_tiles_per_rank(W, H, 3);
+        const size_t ne = (size_t)tiles * 1024;
+        float *d_dir = nullptr, *d_org = nullptr, *d_hits = nullptr, *d_pos = nullptr, *d_nm = nullptr, *d_out = nullptr;
+        CHECK(hipMalloc(&d_dir, ne * 12) == hipSuccess); CHECK(hipMalloc(&d_org, ne * 12) == hipSuccess); CHECK(hipMalloc(&d_hits, 3 * ne * 16) == hipSuccess);
+        CHECK(hipMalloc(&d_pos, ne * 12) == hipSuccess); CHECK(hipMalloc(&d_nm, ne * 16) == hipSuccess); CHECK(hipMalloc(&d_out, 4 * ne * 12) == hipSuccess);
+        CHECK(hipMemset(d_org, 0, ne * 12) == hipSuccess);
+        for (uint32_t r = 0; r < 3; r++) CHECK(rtamd_generate_rays_tiles_device(ctx, W, H, ipv, 0.01f, 1000.f, 0.25f, 0.75f, r, 3, d_dir) == RTAMD_OK);
+        CHECK(rtamd_generate_rays_tiles_device(ctx, W, H, ipv, 0.01f, 1000.f, 0.25f, 0.75f, 3, 3, d_dir) == RTAMD_ERR_INVALID_ARGUMENT);
+        CHECK(rtamd_generate_rays_tiles_device(ctx, W, H, ipv, 0.01f, 1000.f, 0.25f, 0.75f, 0, 1, d_dir) == RTAMD_ERR_INVALID_ARGUMENT);   // whole frame > the shard buffer
+        rtamd_trace_job jobs[17];
+        for (int k = 0; k < 17; k++) jobs[k] = rtamd_trace_job{k % 3 == 2 ? 0u : (uint64_t)(ne - 7 * k), d_org, d_dir, d_hits + (size_t)(k % 3) * ne * 4};
+        for (uint32_t nj : {1u, 3u, 16u}) CHECK(rtamd_trace_batch_device(ctx, nj, jobs) == RTAMD_OK);
+        CHECK(rtamd_trace_batch_device(ctx, 17, jobs) == RTAMD_ERR_INVALID_ARGUMENT);
+        CHECK(rtamd_trace_batch_device(ctx, 0, jobs) == RTAMD_ERR_INVALID_ARGUMENT);
+        jobs[1].n = ne + 1; CHECK(rtamd_trace_batch_device(ctx, 2, jobs) == RTAMD_ERR_INVALID_ARGUMENT); jobs[1].n = ne - 7;   // past the end of org / dir
+        CHECK(rtamd_surface_from_hits_device(ctx, ne, d_org, d_dir, d_hits, 1, d_pos, d_nm) == RTAMD_OK);
+        rtamd_dispatch_desc dd{}; dd.width = W; dd.height = H; dd.position = d_pos; dd.normal_mat = d_nm; dd.light_pos[1] = 10.f; dd.camera_pos[2] = 45.f;
+        dd.noise_offset_scale[2] = 1.f; dd.noise_offset_scale[3] = 1.f; dd.tile_rank = 2; dd.tile_world = 3;
+        rtamd_dispatch_out dout{d_out, d_out + ne * 3, d_out + 2 * ne * 3, d_out + 3 * ne * 3};
+        CHECK(rtamd_dispatch_rays_device(ctx, &dd, &dout) == RTAMD_OK);
+        dd.tile_rank = 3; CHECK(rtamd_dispatch_rays_device(ctx, &dd, &dout) == RTAMD_ERR_INVALID_ARGUMENT);
+        dd.tile_rank = 0; dd.tile_world = 0; CHECK(rtamd_dispatch_rays_device(ctx, &dd, &dout) == RTAMD_ERR_INVALID_ARGUMENT);     // whole frame > the shard buffers
+        CHECK(hipDeviceSynchronize() == hipSuccess);
+        for (float *q : {d_dir, d_org, d_hits, d_pos, d_nm, d_out}) (void)hipFree(q);
+    }
     CHECK(rtamd_abi_version() == RTAMD_ABI_VERSION);
     CHECK(rtamd_set_option(ctx, "no_such", 1) != RTAMD_OK);
     CHECK(hipDeviceSynchronize() == hipSuccess);
