@@ -165,7 +165,7 @@ def main():
                     help="one GPU: batches alternate over that many streams (0 = auto: 2, so that the tail of one batch runs beside the "
                          "start of the next; 1: launches never overlap)")
     ap.add_argument("--gather-batch", type=int, default=0,
-                    help="N > 1: frames per RCCL gather = frames per launch (0 = auto up to 1080p: 8 for 2-4 ranks, 16 beyond; 2 for larger frames)")
+                    help="N > 1: frames per RCCL gather = frames per launch (0 = auto: 8 for 2-4 ranks, 16 beyond at up to 1080p; 8 for larger frames)")
     ap.add_argument("--gather-format", choices=("f32", "rgba8"), default="rgba8",
                     help="N > 1: what crosses xGMI. rgba8 (default) = the display pass's 8-bit back buffer (util/display.frag) that "
                          "every rank produces from its RGBA32F share; f32 = the RGBA32F shares themselves: 33 MB per 1080p frame, "
@@ -236,8 +236,9 @@ def main():
     if world > 1:
         # measured on one GPU (tools/share_cost.py: a rank's 1/8 share of this frame, render + display pass, two alternating streams):
         # 134 us per frame with one frame per launch, 52 us with 4, 37 us with 8
-        # (16 per launch: 33 us).  Auto: a launch of about two whole frames' work — 8 frames up to 4 ranks, 16 beyond
-        B = args.gather_batch if args.gather_batch > 0 else (args.batch if args.batch > 0 else ((8 if world <= 4 else 16) if n_px <= 1920 * 1080 else 2))
+        # (16 per launch: 33 us).  Auto: a launch of about two whole frames' work — 8 frames up to 4 ranks, 16 beyond; 8 for larger
+        # frames (10 M-triangle soup at 4K, a 1/8 share: 786 us per frame with one frame per launch, 550 with 4, 513 with 8)
+        B = args.gather_batch if args.gather_batch > 0 else (args.batch if args.batch > 0 else ((8 if world <= 4 else 16) if n_px <= 1920 * 1080 else 8))
     else:
         # 8 frames per launch (a 20-step run: 8 + 8 + 4, measured equal to five launches of 4 — 0.240 ms per frame — with the
         # per-launch figures of the steady state); 4 only for runs shorter than two such launches
