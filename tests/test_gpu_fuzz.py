@@ -79,11 +79,14 @@ def _rays(rng, tri_pos, n):
 
 @pytest.mark.parametrize("kind", ["grid", "dup", "degenerate", "scales", "soup"])
 def test_random_scenes_trace_and_fused_match_oracle(tracer, oracle_a, kind):
-    rng = np.random.default_rng({"grid": 11, "dup": 12, "degenerate": 13, "scales": 14, "soup": 15}[kind])
+    # RTAMD_FUZZ_SEED / RTAMD_FUZZ_REPS: a soak run with other seeds and more scenes (the committed run: seed 0, 12 scenes per kind)
+    import os
+    seed, reps = int(os.environ.get("RTAMD_FUZZ_SEED", "0")), int(os.environ.get("RTAMD_FUZZ_REPS", "12"))
+    rng = np.random.default_rng({"grid": 11, "dup": 12, "degenerate": 13, "scales": 14, "soup": 15}[kind] + 1000 * seed)
     white = np.full((1, 1, 3), 255, np.uint8)
     tracer.upload_texture(0, white); tracer.upload_texture(1, white)
     try:
-        for rep in range(12):
+        for rep in range(reps):
             sc, tri_pos = _scene(rng, kind)
             n = int(rng.integers(1, 3000))
             org, d = _rays(rng, tri_pos, n)
