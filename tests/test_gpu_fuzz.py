@@ -106,3 +106,75 @@ def test_random_scenes_trace_and_fused_match_oracle(tracer, oracle_a, kind):
                 assert rgb_err_255(a["rgba"][ok], r["rgba"][ok]).max(initial=0.0) <= 0.05, (kind, rep, variant)
     finally:
         tracer.set_kernel_variant(0)
+
+
+def test_random_textured_scenes_match_oracle(tracer, oracle_a):
+    """The shading inputs the other kinds leave out: per-vertex texture coordinates far outside [0, 1] (REPEAT wrap of negative and
+    large coordinates, texel centres hit exactly), interpolated normals that are not unit length or point away from the viewer,
+    two materials, textures of odd sizes down to 1 x 1 and 1 x n.  Hit buffers bit for bit, colour within 0.05/255 of oracle A
+    (the same float bilinear on both sides), both kernel variants."""
+    import os
+    seed, reps = int(os.environ.get("RTAMD_FUZZ_SEED", "0")), int(os.environ.get("RTAMD_FUZZ_REPS", "12"))
+    rng = np.random.default_rng(16 + 1000 * seed)
+    try:
+        for rep in range(reps):
+            n = int(rng.integers(1, 300))
+            tri_pos = rng.uniform(-3, 3, (n, 3, 3)).astype(np.float32)
+            pos = tri_pos.reshape(-1, 3)
+            tri = np.concatenate([np.arange(3 * n, dtype=np.uint32).reshape(n, 3), rng.integers(0, 2, (n, 1)).astype(np.uint32)], axis=1)
+            uv = rng.uniform(-4, 5, (3 * n, 2)).astype(np.float32)
+            snap = rng.random(3 * n) < 0.3
+            uv[snap] = np.round(uv[snap] * 8) / 8                              # texel centres / edges of power-of-two textures, exactly
+            nrm = rng.normal(size=(3 * n, 3)).astype(np.float32)
+            nrm[rng.random(3 * n) < 0.5] *= np.float32(0.01)                    # far from unit length
+            m = host.Model.from_arrays(tri, pos, uv, nrm)
+            m.build_bvh()
+            sc = m.scene_arrays()
+            tex = []
+            for _ in range(2):
+                w, h = [int(x) for x in rng.choice([1, 2, 3, 5, 8, 17, 64], 2)]
+                tex.append(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+            nr = int(rng.integers(1, 3000))
+            org, d = _rays(rng, tri_pos, nr)
+            d[~d.any(axis=1)] = np.float32([0, 0, 1])
+            tracer.upload_scene(sc)
+            tracer.upload_texture(0, tex[0]); tracer.upload_texture(1, tex[1])
+            a = oracle_a.render(sc, d, org, 1, 1, tex[0], tex[1])
+            for variant in (0, 1):
+                tracer.set_kernel_variant(variant)
+                r = tracer.render(nr, 1, dir=d, org=org, has_tex_coords=1, has_normals=1)
+                assert np.array_equal(a["hit_id"], r["hit_id"]) and np.array_equal(bits(a["hit_t"]), bits(r["hit_t"])), (rep, variant)
+                assert np.array_equal(np.isfinite(a["rgba"]), np.isfinite(r["rgba"])), (rep, variant)
+                ok = np.isfinite(a["rgba"]).all(axis=1)
+                assert rgb_err_255(a["rgba"][ok], r["rgba"][ok]).max(initial=0.0) <= 0.05, (rep, variant)
+    finally:
+        tracer.set_kernel_variant(0)
+
+
+def test_random_gbuffers_dispatch_match_oracle(tracer, oracle_a):
+    """ray_dispatcher.frag's restatements against each other on random G-buffers: frame sizes around the kernel's 256-pixel blocks,
+    noise textures of odd sizes, offsets far outside [0, 1], normals of any length, surfaces at the light or the camera (zero-length
+    vectors to normalise), "no surface" pixels anywhere: the four ray arrays bit for bit wherever both are finite, NaN / inf in the same places."""
+    import os
+    seed, reps = int(os.environ.get("RTAMD_FUZZ_SEED", "0")), int(os.environ.get("RTAMD_FUZZ_REPS", "12"))
+    rng = np.random.default_rng(17 + 1000 * seed)
+    for rep in range(reps):
+        w, h = int(rng.integers(1, 300)), int(rng.integers(1, 40))
+        nw, nh = [int(x) for x in rng.choice([1, 2, 3, 7, 16, 64], 2)]
+        noise = rng.integers(0, 256, (nh, nw, 3), dtype=np.uint8)
+        pos = (rng.uniform(-1, 1, (h, w, 3)) * 10.0 ** rng.uniform(-3, 4, (h, w, 1))).astype(np.float32)
+        nm = np.zeros((h, w, 4), np.float32)
+        nm[..., :3] = rng.normal(size=(h, w, 3)) * 10.0 ** rng.uniform(-2, 1, (h, w, 1))
+        nm[..., 3] = np.where(rng.random((h, w)) < 0.2, np.float32(1e30), rng.integers(0, 2, (h, w)).astype(np.uint32).view(np.float32))
+        light = rng.uniform(-20, 20, 3).astype(np.float32)
+        cam = rng.uniform(-20, 20, 3).astype(np.float32)
+        pos[rng.random((h, w)) < 0.02] = light                                  # lightPos - position = 0
+        pos[rng.random((h, w)) < 0.02] = cam                                    # position - cameraPos = 0
+        nos = np.float32([rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(0.1, 9), rng.uniform(0.1, 9)])
+        tracer.upload_noise_texture(noise)
+        r = tracer.dispatch_rays(pos, nm, light, cam, nos)
+        a = oracle_a.dispatch(pos, nm, noise, light, cam, nos)
+        for k in ("org", "shadow_dir", "reflect_dir", "ambient_dir"):
+            fa, fr = np.isfinite(a[k]), np.isfinite(r[k])
+            assert np.array_equal(fa, fr), (rep, k)
+            assert np.array_equal(bits(a[k])[fa], bits(r[k])[fa]), (rep, k, w, h)
