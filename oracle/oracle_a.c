@@ -66,6 +66,8 @@ typedef struct { const uint8_t *rgb; int w, h; } oa_texture;
 /* options --------------------------------------------------------------- */
 static int g_flush_denormals = 1;   /* set MXCSR FTZ|DAZ in the worker (llvmpipe rasteriser threads do) */
 void oa_set_flush_denormals(int on) { g_flush_denormals = on; }
+static int g_edge_sum_as_written = 0;   /* 1: evaluate :83 as the rounded sum of the two products (negative control of golden_edge) */
+void oa_set_edge_sum_as_written(int on) { g_edge_sum_as_written = on; }
 /* deepest shader-stack occupancy seen since the last reset (statistics only; racy max is fine) */
 static volatile uint32_t g_max_stack = 0;
 uint32_t oa_max_stack(int reset) { uint32_t v = g_max_stack; if (reset) g_max_stack = 0; return v; }
@@ -123,11 +125,18 @@ static inline float oa_tri(const oa_ray *ray, v3 p0, v3 p1, v3 p2, v2 *uv) {
     if (fabsf(a) < OA_EPSILON) return -1.0f;
     float f = 1.0f / a;
     v3 s = oa_sub(ray->org, p0);
-    uv->x = f * oa_dot(s, h);
+    const float du = oa_dot(s, h);
+    uv->x = f * du;
     if (uv->x < 0.0f || uv->x > 1.0f) return -1.0f;
     v3 q = oa_cross(s, edge1);
-    uv->y = f * oa_dot(ray->dir, q);
-    if (uv->y < 0.0f || uv->x + uv->y > 1.0f) return -1.0f;
+    const float dv = oa_dot(ray->dir, q);
+    uv->y = f * dv;
+    /* `uv.x + uv.y > 1.0` (:83) AS THE PINNED REFERENCE EXECUTES IT: Mesa's NIR algebraic pass factors f*du + f*dv into
+     * f*(du + dv) (GLSL allows it without `precise`; ST_DEBUG=nir shows `fadd du, dv; fmul f, .; flt 1.0, .` in both
+     * shaders), which decides differently from the rounded sum of the two products for rays within an ulp of the edge
+     * u + v = 1.  Found by tests/golden/soak_oracle_vs_llvmpipe.py; pinned by tests/golden/golden_edge.npz. */
+    const float edge = g_edge_sum_as_written ? uv->x + uv->y : f * (du + dv);
+    if (uv->y < 0.0f || edge > 1.0f) return -1.0f;
     return f * oa_dot(edge2, q);
 }
 

@@ -36,7 +36,8 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 
-from oracles import OracleB  # noqa: E402
+from common import bits  # noqa: E402
+from oracles import OracleA, OracleB  # noqa: E402
 from raytracer_amd import host  # noqa: E402
 
 REF = "/root/reference/res"
@@ -251,6 +252,63 @@ def dispatch2():
     print("dispatch2:", int(surface.sum()), "surface pixels of", w * h, "materials", np.unique(gnm[..., 3][surface].view(np.uint32)), "->", os.path.getsize(path) / 1e6, "MB")
 
 
+def edge():
+    """Rays aimed at the edges and vertices of triangles (round 2): the decisions of intersectTriangle (:72, :78, :83) within an ulp
+    of the boundary.  On the edge u + v = 1 the reference's compiler (Mesa NIR) evaluates f*du + f*dv as f*(du + dv); the fixture
+    holds rays on which the two forms decide differently (counted below with the oracle's switch), so it pins that.  No ray passes
+    through the coordinate origin (the scene is shifted): see llvmpipe_origin_artifact.py."""
+    A = OracleA()
+    B = OracleB()
+    rng = np.random.default_rng(83)
+    n_tri = 48
+    tri_pos = (rng.uniform(-3, 3, (n_tri, 3, 3)) + np.array([7.0, 5.0, 3.0])).astype(np.float32)
+    tri = np.concatenate([np.arange(3 * n_tri, dtype=np.uint32).reshape(n_tri, 3), rng.integers(0, 2, (n_tri, 1)).astype(np.uint32)], axis=1)
+    m = host.Model.from_arrays(tri, tri_pos.reshape(-1, 3))
+    m.build_bvh()
+    sc = m.scene_arrays()
+
+    def aimed(n):
+        t = tri_pos[rng.integers(0, n_tri, n)].astype(np.float64)
+        w = rng.dirichlet([1, 1, 1], n)
+        kind = rng.random(n)
+        on_hyp = kind < 0.7                                         # p1..p2: u + v = 1
+        w[on_hyp, 0] = 0.0
+        on_u0 = (kind >= 0.7) & (kind < 0.8)                        # p0..p2: u = 0
+        w[on_u0, 1] = 0.0
+        on_v0 = (kind >= 0.8) & (kind < 0.9)                        # p0..p1: v = 0
+        w[on_v0, 2] = 0.0
+        vert = kind >= 0.9
+        w[vert] = np.eye(3)[rng.integers(0, 3, int(vert.sum()))]
+        w /= w.sum(1, keepdims=True)
+        target = (t * w[:, :, None]).sum(1)
+        org = target + rng.normal(0, 1, (n, 3)) * rng.uniform(0.5, 6, (n, 1))
+        d = target - org
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        return org.astype(np.float32), d.astype(np.float32)
+
+    # many candidates; keep every ray on which the two forms of :83 decide differently, fill up with the rest
+    org, d = aimed(300000)
+    as_compiled = A.trace(sc, org, d)["hits"]
+    A.set_edge_sum_as_written(1)
+    as_written = A.trace(sc, org, d)["hits"]
+    A.set_edge_sum_as_written(0)
+    differ = np.where((bits(as_compiled) != bits(as_written)).any(axis=1))[0]
+    hh = ww = 64
+    differ = differ[:hh * ww // 2]
+    rest = np.setdiff1d(np.arange(len(org)), differ)[:hh * ww - len(differ)]
+    pick = np.concatenate([differ, rest])
+    rng.shuffle(pick)
+    orgs, dirs = org[pick].reshape(hh, ww, 3), d[pick].reshape(hh, ww, 3)
+    b_trace, _ = B.trace(sc, dirs, orgs)
+    b_fused, _ = B.fused(sc, dirs, orgs, False, False, None, None)
+    path = os.path.join(HERE, "golden_edge.npz")
+    np.savez_compressed(path, nodes=sc["nodes"], triangles=sc["triangles"], positions=sc["positions"], dir=dirs, org=orgs,
+                        b_trace=b_trace, b_fused=b_fused, n_discriminating=np.int32(len(differ)), renderer=np.array(B.renderer))
+    got = A.trace(sc, orgs, dirs)["hits"]
+    print("edge:", len(differ), "rays of", hh * ww, "on which u + v as written decides differently;",
+          "oracle A == llvmpipe:", np.array_equal(bits(got), bits(b_trace.reshape(-1, 4))), "->", os.path.getsize(path) / 1e3, "kB")
+
+
 def atrium():
     """The headline scene (bench.py's atrium_1080p, BASELINE config 3) at 240x135: the scene is procedural and
     deterministic (raytracer_amd/scenes.py + the host BVH builder), so only the shader outputs are stored; the
@@ -330,6 +388,8 @@ if __name__ == "__main__":
         dispatch2()
     elif "--only-more-models" in sys.argv:
         main(MORE_CASES, with_extras=False)
+    elif "--only-edge" in sys.argv:
+        edge()
     elif "--only-raycreate" in sys.argv:
         raycreate()
     elif "--only-atrium" in sys.argv:

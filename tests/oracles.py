@@ -110,6 +110,10 @@ class OracleA:
     def set_flush_denormals(self, on):
         self.L.oa_set_flush_denormals(int(on))
 
+    def set_edge_sum_as_written(self, on):
+        """1: the test of ray_trace.frag / ray_trace_and_shade.frag:83 as the rounded sum u + v, not as the reference's compiler factors it."""
+        self.L.oa_set_edge_sum_as_written(int(on))
+
     def render(self, scene, dir, org, has_tex_coords, has_normals, tex0=None, tex1=None, nthreads=1):
         """Returns dict(rgba, hit_id, hit_t, counts, shadow, overflow) for n = dir.size/3 pixels."""
         keep = []

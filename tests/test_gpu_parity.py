@@ -38,6 +38,27 @@ def test_trace_special_values(tracer):
     assert np.array_equal(bits(hits), bits(g["b_trace"].reshape(-1, 4)))
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+def test_rays_on_triangle_edges(tracer, variant):
+    """golden_edge: the decisions of intersectTriangle within an ulp of an edge or a vertex, against llvmpipe's records and
+    colours; half of the rays separate `u + v` as written from the compiler's f*(du + dv) (tests/test_oracle_golden.py)."""
+    g = load_golden("edge")
+    tracer.upload_scene({"nodes": g["nodes"], "triangles": g["triangles"], "positions": g["positions"]})
+    tracer.set_kernel_variant(variant)
+    try:
+        hits = tracer.trace(g["org"], g["dir"])
+        h, w = g["dir"].shape[:2]
+        r = tracer.render(w, h, dir=g["dir"], org=g["org"], has_tex_coords=0, has_normals=0, want=("rgba", "hit_id", "hit_t"))
+    finally:
+        tracer.set_kernel_variant(0)
+    want = g["b_trace"].reshape(-1, 4)
+    assert np.array_equal(bits(hits), bits(want))
+    hit = want[:, 0] < 1000
+    assert np.array_equal(bits(r["hit_t"].reshape(-1)[hit]), bits(want[hit, 0]))
+    assert np.array_equal(r["hit_id"].reshape(-1)[hit], want[hit, 3].view(np.uint32))
+    assert rgb_err_255(r["rgba"].reshape(-1, 4), g["b_fused"].reshape(-1, 4)).max() <= 1.0
+
+
 @pytest.mark.parametrize("anyhit", [0, 1])
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("name", GOLDEN_SCENES)
