@@ -453,21 +453,35 @@ int oa_trace(const oa_scene *sc, uint64_t n, const float *org, const float *dir,
 /* ray_create.frag:12 evaluated at (off_x, off_y) inside each pixel, row 0 = bottom.  (0.5, 0.5) is the pixel centre
  * the reference rasterises (quad-11.vert:8); other offsets are the jittered samples of multi-sample frames, which the
  * reference does not have (one sample per pixel). */
+/* ray_create.frag:12 for one value of the varying fragPos = (x, y) */
+static inline v3 oa_raycreate_one(const float *m, float near_, float far_, float x, float y) {
+    float v[4] = { x * far_ - x * near_, y * far_ - y * near_, 1.0f * far_ - (-1.0f) * near_, 1.0f * far_ - 1.0f * near_ };
+    v3 d;
+    float r[3];
+    for (int k = 0; k < 3; k++) r[k] = ((m[0 + k] * v[0] + m[4 + k] * v[1]) + m[8 + k] * v[2]) + m[12 + k] * v[3];
+    d.x = r[0]; d.y = r[1]; d.z = r[2];
+    return oa_normalize(d);
+}
+
 void oa_raycreate_offset(uint32_t w, uint32_t h, const float *m /* column-major invProjView */, float near_, float far_,
                          float off_x, float off_y, float *dir_out) {
     for (uint32_t py = 0; py < h; py++) {
         float y = ((float)py + off_y) / (float)h * 2.0f - 1.0f;
         for (uint32_t px = 0; px < w; px++) {
             float x = ((float)px + off_x) / (float)w * 2.0f - 1.0f;
-            float v[4] = { x * far_ - x * near_, y * far_ - y * near_, 1.0f * far_ - (-1.0f) * near_, 1.0f * far_ - 1.0f * near_ };
-            v3 d;
-            float r[3];
-            for (int k = 0; k < 3; k++) r[k] = ((m[0 + k] * v[0] + m[4 + k] * v[1]) + m[8 + k] * v[2]) + m[12 + k] * v[3];
-            d.x = r[0]; d.y = r[1]; d.z = r[2];
-            d = oa_normalize(d);
+            const v3 d = oa_raycreate_one(m, near_, far_, x, y);
             float *o = dir_out + 3 * ((size_t)py * w + px);
             o[0] = d.x; o[1] = d.y; o[2] = d.z;
         }
+    }
+}
+
+/* The same for n explicit values of the varying (frag_pos: n x 2).  The varying is the rasteriser's product, not the
+ * shader's: tests/golden/soak_oracle_vs_llvmpipe.py reads llvmpipe's own values back and checks the shader arithmetic on them. */
+void oa_raycreate_points(uint64_t n, const float *frag_pos, const float *m, float near_, float far_, float *dir_out) {
+    for (uint64_t i = 0; i < n; i++) {
+        const v3 d = oa_raycreate_one(m, near_, far_, frag_pos[2 * i], frag_pos[2 * i + 1]);
+        dir_out[3 * i] = d.x; dir_out[3 * i + 1] = d.y; dir_out[3 * i + 2] = d.z;
     }
 }
 

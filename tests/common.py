@@ -125,12 +125,14 @@ def soup_golden():
 def check_raycreate(generate):
     """generate(w, h, inv_proj_view16, near, far) -> (h*w, 3) directions, checked against the llvmpipe runs of
     ray_trace/ray_create.frag in tests/golden/golden_raycreate.npz: the shader uses the rasteriser's interpolated
-    fragPos, so 95+ % of the components are bit-equal and the rest within 2e-5."""
+    fragPos, so 95+ % of the components are bit-equal and the rest within 2e-5 (3e-4 for the camera far from the origin,
+    whose unprojection cancels more).  The shader's arithmetic itself is pinned bit for bit on llvmpipe's own fragPos values:
+    tests/test_oracle_golden.py:test_ray_create_arithmetic_bit_exact_on_the_rasterisers_frag_pos."""
     g = load_golden("raycreate")
     near, far = (float(x) for x in g["near_far"])
     for k in range(int(g["count"])):
         w, h = (int(x) for x in g[f"size{k}"])
         want = g[f"b_dir{k}"].reshape(-1, 3)
         got = np.asarray(generate(w, h, g[f"inv_proj_view{k}"], near, far), np.float32).reshape(-1, 3)
-        assert np.abs(got - want).max() <= 2e-5, (k, float(np.abs(got - want).max()))
+        assert np.abs(got - want).max() <= (2e-5 if k < 3 else 3e-4), (k, float(np.abs(got - want).max()))
         assert (bits(got) == bits(want)).mean() >= 0.95, k

@@ -362,19 +362,39 @@ def soup():
 
 
 def raycreate():
-    """ray_trace/ray_create.frag on llvmpipe for three cameras: inputs (inverse proj*view, near, far) and the RGB32F
+    """ray_trace/ray_create.frag on llvmpipe for four cameras: inputs (inverse proj*view, near, far) and the RGB32F
     direction target.  The shader works on the rasteriser's interpolated fragPos, ours on pixel centres computed in
-    float: 96-100 % of the components are bit-equal, the rest within 1.5e-5 (tests use 2e-5)."""
+    float: 96-100 % of the components are bit-equal, the rest within 1.5e-5 for the first three cameras and 2.1e-4 for the
+    fourth (far from the origin: the unprojection cancels more).  Round 2 also stores llvmpipe's OWN values of the varying
+    (b_fragpos: the same draw with the shader's one statement replaced by `dir = vec3(fragPos, 0)`, patched in a temporary
+    copy), so that the shader's arithmetic is pinned bit for bit on every pixel: oracle(b_fragpos) == b_dir."""
+    import shutil
+    import tempfile
+    from oracles import REFERENCE_SHADERS
     B = OracleB()
+    root = tempfile.mkdtemp(prefix="rtamd_shaders_")
+    shutil.rmtree(root)
+    shutil.copytree(REFERENCE_SHADERS, root)
+    frag = os.path.join(root, "ray_trace", "ray_create.frag")
+    text = open(frag).read()
+    statement = "dir = normalize((invProjView * (vec4(fragPos, 1, 1) * far - vec4(fragPos, -1, 1) * near)).xyz);"
+    assert text.count(statement) == 1
+    open(frag, "w").write(text.replace(statement, "dir = vec3(fragPos, 0);"))
     out = {}
-    cams = [(240, 135, (0.5, 1.5, -2.0), (0.2, -0.1, 0.97), 75.0), (160, 120, (3.0, 4.0, 5.0), (-0.5, -0.4, -0.6), 120.0), (64, 64, (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 30.0)]
+    cams = [(240, 135, (0.5, 1.5, -2.0), (0.2, -0.1, 0.97), 75.0), (160, 120, (3.0, 4.0, 5.0), (-0.5, -0.4, -0.6), 120.0), (64, 64, (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 30.0),
+            (320, 180, (31.0, -42.0, 25.5), (-0.55, 0.62, -0.56), 95.0)]
     for k, (w, h, pos, d, fov) in enumerate(cams):
         dd = np.asarray(d, np.float32)
         dd /= np.linalg.norm(dd)
         cam = host.Camera(w / h, fov=math.radians(fov), position=pos, direction=dd)
         inv = np.asarray(cam.inv_proj_view(), np.float32).reshape(16)
+        assert B.L.glslref_init(REFERENCE_SHADERS.encode()) == 0
         b = np.asarray(B.raycreate(w, h, inv, host.NEAR, host.FAR), np.float32).reshape(h, w, -1)[..., :3]
+        assert B.L.glslref_init(root.encode()) == 0
+        fp = np.asarray(B.raycreate(w, h, inv, host.NEAR, host.FAR), np.float32).reshape(h, w, -1)[..., :2]
         out[f"size{k}"] = np.int32([w, h]); out[f"inv_proj_view{k}"] = inv; out[f"b_dir{k}"] = np.ascontiguousarray(b)
+        out[f"b_fragpos{k}"] = np.ascontiguousarray(fp)
+    assert B.L.glslref_init(REFERENCE_SHADERS.encode()) == 0
     out["near_far"] = np.float32([host.NEAR, host.FAR]); out["count"] = np.int32(len(cams)); out["renderer"] = np.array(B.renderer)
     path = os.path.join(HERE, "golden_raycreate.npz")
     np.savez_compressed(path, **out)

@@ -32,6 +32,9 @@ def through_origin(org, d):
     """The slab test of ray_trace_and_shade.frag:53-61 against a box of zeros with t = 1000000, in float32; rays with a zero
     direction component (0 * inf) count as through the origin when the other axes allow it."""
     with np.errstate(all="ignore"):
+        tiny = np.float32(1.1754944e-38)                    # llvmpipe runs FTZ / DAZ: denormal components are zeros
+        org = np.where(np.abs(org) < tiny, np.copysign(np.float32(0), org), org)
+        d = np.where(np.abs(d) < tiny, np.copysign(np.float32(0), d), d)
         tx = ((np.float32(0) - org) * (np.float32(1) / d)).astype(np.float32)
         tmin, tmax = np.nanmax(tx, axis=1), np.nanmin(tx, axis=1)
         return np.isnan(tx).all(axis=1) | ((tmax >= tmin) & (tmax > 0))
@@ -43,6 +46,30 @@ A, B = OracleA(), OracleB()
 A.set_flush_denormals(1)
 print("reference:", B.renderer)
 bad = n_origin = n_group = 0
+def check_colour(kind, rep, sc, org, d2, a, fused, args, tol=1.0):
+    """Shared by the plain and the textured part: colour within tol/255 (a number or one per pixel), the origin artefact counted apart."""
+    global bad, n_origin, n_group
+    fused = fused.reshape(-1, 4)
+    tol = np.broadcast_to(np.asarray(tol, np.float64), (len(fused),))
+    ok = np.isfinite(fused).all(axis=1) & np.isfinite(a["rgba"]).all(axis=1)
+    err = np.where(ok, rgb_err_255(a["rgba"], np.where(ok[:, None], fused, a["rgba"])), 0.0)
+    origin = through_origin(org, d2)
+    for i in np.where(err > tol)[0]:
+        alone, _ = B.fused(sc, d2[i].reshape(1, 1, 3), org[i].reshape(1, 1, 3), *args)
+        e1 = rgb_err_255(a["rgba"][i:i + 1], alone.reshape(1, 4))[0]
+        if e1 <= tol[i] and a["shadow"][i] == 1:
+            n_group += 1
+            err[i] = e1
+        elif origin[i] and a["shadow"][i] == 1:
+            n_origin += 1
+            err[i] = 0.0
+    if (err > tol).any() or not np.array_equal(np.isfinite(fused).all(axis=1), np.isfinite(a["rgba"]).all(axis=1)):
+        bad += 1
+        k = int((err - tol).argmax())
+        print(f"MISMATCH colour {kind} rep {rep}: {err[k]:.3f}/255 (allowed {tol[k]:.3f}) at ray {k}: oracle {a['rgba'][k]} reference {fused[k]} org {org[k]} dir {d2[k]}")
+    return float(err.max(initial=0.0))
+
+
 for kind in ("grid", "dup", "degenerate", "scales", "soup"):
     rng = np.random.default_rng({"grid": 11, "dup": 12, "degenerate": 13, "scales": 14, "soup": 15}[kind] + 1000 * seed)
     n_rays = n_hit = 0
@@ -64,28 +91,135 @@ for kind in ("grid", "dup", "degenerate", "scales", "soup"):
         fused, _ = B.fused(sc, d2.reshape(n, 1, 3), o3, False, False, None, None)
         a = A.render(sc, d2, org, 0, 0)
         fused = fused.reshape(-1, 4)
-        ok = np.isfinite(fused).all(axis=1) & np.isfinite(a["rgba"]).all(axis=1)
-        err = np.where(ok, rgb_err_255(a["rgba"], np.where(ok[:, None], fused, a["rgba"])), 0.0)
-        origin = through_origin(org, d2)
-        for i in np.where(err > 1.0)[0]:
-            alone, _ = B.fused(sc, d2[i].reshape(1, 1, 3), org[i].reshape(1, 1, 3), False, False, None, None)
-            e1 = rgb_err_255(a["rgba"][i:i + 1], alone.reshape(1, 4))[0]
-            lit_instead_of_shadow = a["shadow"][i] == 1
-            if e1 <= 1.0 and lit_instead_of_shadow:
-                n_group += 1        # the neighbour's artefact: alone, the pixel agrees
-                err[i] = e1
-            elif origin[i] and lit_instead_of_shadow:
-                n_origin += 1
-                err[i] = 0.0
-        e = err.max(initial=0.0)
-        worst = max(worst, float(e))
-        if e > 1.0 or not np.array_equal(np.isfinite(fused).all(axis=1), np.isfinite(a["rgba"]).all(axis=1)):
-            bad += 1
-            k = int(err.argmax())
-            print(f"MISMATCH colour {kind} rep {rep}: max {e:.3f}/255 at ray {k}: oracle {a['rgba'][k]} reference {fused[k]} org {org[k]} dir {d2[k]}")
+        worst = max(worst, check_colour(kind, rep, sc, org, d2, a, fused, (False, False, None, None)))
         n_rays += n
         n_hit += int((ref[:, 0] < 1e30).sum())
     print(f"{kind}: {reps} scenes, {n_rays} rays, {n_hit} hits, worst colour difference {worst:.4f}/255")
+
+
+# textured scenes with interpolated normals (tests/test_gpu_fuzz.py:test_random_textured_scenes_match_oracle).  Texture rows are
+# multiples of 4 bytes: the reference uploads tightly packed RGB rows with GL's default UNPACK_ALIGNMENT of 4
+# (src/gl_wrapper/texture.rs:11-26), so other widths reach GL skewed and read past the image -- nothing to pin there.
+from raytracer_amd import host  # noqa: E402
+rng = np.random.default_rng(16 + 1000 * seed)
+worst = 0.0
+n_rays = 0
+for rep in range(reps):
+    n = int(rng.integers(1, 300))
+    tri_pos = rng.uniform(-3, 3, (n, 3, 3)).astype(np.float32)
+    tri = np.concatenate([np.arange(3 * n, dtype=np.uint32).reshape(n, 3), rng.integers(0, 2, (n, 1)).astype(np.uint32)], axis=1)
+    uv = rng.uniform(-4, 5, (3 * n, 2)).astype(np.float32)
+    snap = rng.random(3 * n) < 0.3
+    uv[snap] = np.round(uv[snap] * 8) / 8
+    nrm = rng.normal(size=(3 * n, 3)).astype(np.float32)
+    nrm[rng.random(3 * n) < 0.5] *= np.float32(0.01)
+    m = host.Model.from_arrays(tri, tri_pos.reshape(-1, 3), uv, nrm)
+    m.build_bvh()
+    sc = m.scene_arrays()
+    # llvmpipe filters RGBA8 in 8-bit fixed point and RETURNS 8-bit values (albedo * 255 comes out integral): against the float
+    # bilinear of the oracle that is up to 0.8/255 on a smooth image and up to 2/255 between texels of full contrast (8-bit
+    # weights on both axes), and the shader multiplies the albedo by ambient + diffuse light of up to 1.7.  The allowed colour
+    # difference is therefore the pixel's light (the oracle's colour under a white texture, at least 1) times 1/255 for the
+    # smooth image and 2.2/255 for white noise; the committed fixtures (real model textures) stay within 1/255.
+    tw, th = int(rng.choice([16, 32, 64])), int(rng.choice([1, 16, 64]))
+    yy, xx = np.meshgrid(np.arange(th), np.arange(tw), indexing="ij")
+    smooth = np.stack([128 + 90 * np.sin(2 * np.pi * (xx / tw + k / 3)) * np.cos(2 * np.pi * yy / th) for k in range(3)], axis=-1).astype(np.uint8)
+    noise = rng.integers(0, 256, (int(rng.choice([1, 2, 3, 5, 8, 17, 64])), int(rng.choice([4, 8, 12, 16, 64])), 3), dtype=np.uint8)
+    nr = int(rng.integers(1, 3000))
+    org, d = _rays(rng, tri_pos, nr)
+    d[~d.any(axis=1)] = np.float32([0, 0, 1])
+    light = A.render(sc, d, org, 1, 1, None, None)["rgba"][:, :3]
+    tol = np.maximum(1.0, np.nan_to_num(light, nan=1.0, posinf=1.0, neginf=1.0).max(axis=1))
+    # one material image in both slots: llvmpipe's sampler index is per 4x4 block ("Colour is pinned")
+    for t, albedo_tol in ((smooth, 1.0), (noise, 2.2)):
+        args = (True, True, t, t)
+        fused, _ = B.fused(sc, d.reshape(nr, 1, 3), org.reshape(nr, 1, 3), *args)
+        a = A.render(sc, d, org, 1, 1, t, t)
+        worst = max(worst, check_colour("textured", rep, sc, org, d, a, fused, args, tol * albedo_tol))
+    n_rays += 2 * nr
+print(f"textured + interpolated normals: {reps} scenes, {n_rays} rays, worst colour difference {worst:.4f}/255")
+
+# ray_dispatcher.frag on random G-buffers (tests/test_gpu_fuzz.py:test_random_gbuffers_dispatch_match_oracle), the noise texture
+# sampled at texel centres as src/main.rs:161-165 sets it up (between texels llvmpipe filters RGBA8 with 8-bit weights, the
+# oracle in float: implementation-defined in GL).  org / shadowDir / reflectDir bit for bit, NaN and inf in the same places;
+# ambientDir within 1e-3 (a coordinate a few ulps off a texel centre already changes llvmpipe's 8-bit weight, and
+# normalize(normal + random * 2 - 1) magnifies that where the sum is short; worst seen 3.3e-4).
+rng = np.random.default_rng(17 + 1000 * seed)
+n_px = 0
+worst_ambient = 0.0
+for rep in range(reps):
+    w, h = int(rng.integers(1, 300)), int(rng.integers(1, 40))
+    nw, nh = int(rng.choice([4, 8, 12, 16, 20, 64])), int(rng.choice([1, 2, 3, 7, 16, 64]))
+    noise = rng.integers(0, 256, (nh, nw, 3), dtype=np.uint8)
+    pos = (rng.uniform(-1, 1, (h, w, 3)) * 10.0 ** rng.uniform(-3, 4, (h, w, 1))).astype(np.float32)
+    nm = np.zeros((h, w, 4), np.float32)
+    nm[..., :3] = rng.normal(size=(h, w, 3)) * 10.0 ** rng.uniform(-2, 1, (h, w, 1))
+    nm[..., 3] = np.where(rng.random((h, w)) < 0.2, np.float32(1e30), rng.integers(0, 2, (h, w)).astype(np.uint32).view(np.float32))
+    light = rng.uniform(-20, 20, 3).astype(np.float32)
+    cam = rng.uniform(-20, 20, 3).astype(np.float32)
+    pos[rng.random((h, w)) < 0.02] = light
+    pos[rng.random((h, w)) < 0.02] = cam
+    nos = np.float32([np.float32(rng.integers(0, nw)) / np.float32(nw), np.float32(rng.integers(0, nh)) / np.float32(nh),
+                      np.float32(w) / np.float32(nw), np.float32(h) / np.float32(nh)])
+    a = A.dispatch(pos, nm, noise, light, cam, nos)
+    b = B.dispatch(pos, nm, noise, light, cam, nos)
+    n_px += w * h
+    for k in ("org", "shadow_dir", "reflect_dir", "ambient_dir"):
+        fa, fb = np.isfinite(a[k]), np.isfinite(b[k])
+        if k == "ambient_dir":
+            diff = np.abs(np.where(fa & fb, a[k], 0) - np.where(fa & fb, b[k], 0)).max(initial=0.0)
+            worst_ambient = max(worst_ambient, float(diff))
+            wrong = not np.array_equal(fa, fb) or diff > 1e-3
+        else:
+            wrong = not np.array_equal(fa, fb) or not np.array_equal(bits(a[k])[fa], bits(b[k])[fa])
+        if wrong:
+            bad += 1
+            print(f"MISMATCH dispatcher rep {rep}: {k}")
+print(f"dispatcher: {reps} G-buffers, {n_px} pixels, worst ambientDir difference {worst_ambient:.2e}")
+
+# ray_create.frag with random cameras and frame sizes.  The varying fragPos is the rasteriser's (llvmpipe evaluates a plane
+# equation; most values differ from the correctly rounded pixel centre by some 1e-7), so llvmpipe's own values are read back
+# from the same draw with a patched copy of the shader: on them the restatement must give llvmpipe's directions bit for bit.
+import math  # noqa: E402
+import shutil  # noqa: E402
+import tempfile  # noqa: E402
+from oracles import REFERENCE_SHADERS  # noqa: E402
+root = tempfile.mkdtemp(prefix="rtamd_shaders_")
+shutil.rmtree(root)
+shutil.copytree(REFERENCE_SHADERS, root)
+frag = os.path.join(root, "ray_trace", "ray_create.frag")
+text = open(frag).read()
+statement = "dir = normalize((invProjView * (vec4(fragPos, 1, 1) * far - vec4(fragPos, -1, 1) * near)).xyz);"
+assert text.count(statement) == 1
+open(frag, "w").write(text.replace(statement, "dir = vec3(fragPos, 0);"))
+rng = np.random.default_rng(18 + 1000 * seed)
+n_px = n_off = 0
+worst_centre = 0.0
+for rep in range(reps):
+    w, h = (int(rng.integers(1, 400)), int(rng.integers(1, 300))) if rep % 4 else [(640, 480), (1920, 1080), (240, 135)][(rep // 4) % 3]
+    direction = rng.normal(size=3)
+    direction /= np.linalg.norm(direction)
+    if abs(direction[1]) > 0.99:
+        direction = np.array([0.6, 0.0, 0.8])
+    cam = host.Camera(w / h, fov=math.radians(rng.uniform(5, 170)), position=rng.uniform(-50, 50, 3).astype(np.float32), direction=direction.astype(np.float32))
+    inv = np.asarray(cam.inv_proj_view(), np.float32).reshape(16)
+    assert B.L.glslref_init(REFERENCE_SHADERS.encode()) == 0
+    b = np.asarray(B.raycreate(w, h, inv, host.NEAR, host.FAR), np.float32).reshape(h, w, -1)[..., :3]
+    assert B.L.glslref_init(root.encode()) == 0
+    fp = np.asarray(B.raycreate(w, h, inv, host.NEAR, host.FAR), np.float32).reshape(h, w, -1)[..., :2]
+    a = A.raycreate_points(fp, inv, host.NEAR, host.FAR)
+    centre = A.raycreate(w, h, inv, host.NEAR, host.FAR)
+    n_px += w * h
+    n_off += int((bits(centre) != bits(b)).any(axis=-1).sum())
+    worst_centre = max(worst_centre, float(np.abs(centre - b).max()))
+    if not np.array_equal(bits(a), bits(b)):
+        bad += 1
+        k = np.argwhere((bits(a) != bits(b)).any(axis=-1))
+        print(f"MISMATCH ray_create rep {rep}: {len(k)} of {w * h} pixels, first {k[0]}: oracle {a[tuple(k[0])]} reference {b[tuple(k[0])]}")
+assert B.L.glslref_init(REFERENCE_SHADERS.encode()) == 0
+print(f"(from correctly rounded pixel centres instead of llvmpipe's fragPos: {n_off} pixels differ, by at most {worst_centre:.2e})")
+print(f"ray_create: {reps} cameras, {n_px} pixels")
+
 print(f"llvmpipe origin artefact (not counted): {n_origin} pixels whose own ray passes through (0,0,0), {n_group} pixels that agree when drawn alone")
 print("FAILED" if bad else "ok", bad)
 sys.exit(1 if bad else 0)

@@ -178,6 +178,15 @@ class OracleA:
         self.L.oa_raycreate_offset(width, height, m.ctypes.data, near, far, float(offset[0]), float(offset[1]), out.ctypes.data)
         return out
 
+    def raycreate_points(self, frag_pos, inv_proj_view, near, far):
+        """ray_create.frag on explicit values of the varying fragPos (..., 2) -> directions (..., 3)."""
+        m = np.ascontiguousarray(inv_proj_view, dtype=np.float32).reshape(16)
+        fp = np.ascontiguousarray(frag_pos, dtype=np.float32)
+        out = np.zeros(fp.shape[:-1] + (3,), np.float32)
+        self.L.oa_raycreate_points(ctypes.c_uint64(fp.size // 2), ctypes.c_void_p(fp.ctypes.data), ctypes.c_void_p(m.ctypes.data),
+                                   ctypes.c_float(near), ctypes.c_float(far), ctypes.c_void_p(out.ctypes.data))
+        return out
+
 
 class OracleB:
     """llvmpipe; arrays are (h, w, c) with row 0 = bottom row (GL convention)."""
