@@ -234,6 +234,16 @@ static v3 oa_skybox(v3 dir) {
 /* texture(sampler2D, uv).xyz for an RGBA8-unorm, LINEAR, REPEAT, single-level
  * texture whose rows were uploaded first-row-first (texture.rs:11-26). */
 static inline int wrap_repeat(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+/* unorm8 -> float as llvmpipe converts it: a multiplication by fl(1/255), not the division (the two differ in the last bit for
+ * 126 of the 256 values).  With it the dispatcher's ambient directions equal llvmpipe's bit for bit (golden_dispatch*.npz). */
+#define OA_UNORM8 (1.0f / 255.0f)
+static int g_filter_8bit = 0;
+/* 0 (default): float bilinear, what the library computes.  1: the filter as Mesa llvmpipe executes it on an RGBA8 texture --
+ * weights rounded to 8 bits, three 8-bit lerps (x on both rows, then y) each rounded to 8 bits, the result an 8-bit value --
+ * found by probing its sampler (tests/golden/soak_oracle_vs_llvmpipe.py describes the probe: 100 % of 1.8 M samples equal).
+ * Test-only: it shows that what is left between the oracle and llvmpipe on textured pixels is this filter and nothing else. */
+void oa_set_texture_filter_8bit(int on) { g_filter_8bit = on; }
+
 static v3 oa_sample_albedo(const oa_texture *tex, float s, float t) {
     v3 out;
     const int W = tex->w, H = tex->h;
@@ -245,14 +255,53 @@ static v3 oa_sample_albedo(const oa_texture *tex, float s, float t) {
     const uint8_t *t00 = tex->rgb + 3 * ((size_t)j0 * W + i0), *t10 = tex->rgb + 3 * ((size_t)j0 * W + i1);
     const uint8_t *t01 = tex->rgb + 3 * ((size_t)j1 * W + i0), *t11 = tex->rgb + 3 * ((size_t)j1 * W + i1);
     float c[3];
+    if (g_filter_8bit) {
+        /* unless BOTH dimensions are powers of two, coordinates are wrapped BEFORE they are scaled (fract(s), clamped below 1):
+         * the same texel pair, but the products round at another magnitude, which moves a weight at a near-tie */
+        const int npot = (W & (W - 1)) || (H & (H - 1));
+        if (npot) {
+            float fs = s - floorf(s);
+            if (fs >= 1.0f) fs = 0.99999994f;
+            u = fs * (float)W - 0.5f; fu = floorf(u); a = u - fu;
+            i0 = wrap_repeat((int)fu, W); i1 = wrap_repeat(i0 + 1, W);
+        }
+        if (npot) {
+            float ft = t - floorf(t);
+            if (ft >= 1.0f) ft = 0.99999994f;
+            v = ft * (float)H - 0.5f; fv = floorf(v); b = v - fv;
+            j0 = wrap_repeat((int)fv, H); j1 = wrap_repeat(j0 + 1, H);
+        }
+        t00 = tex->rgb + 3 * ((size_t)j0 * W + i0); t10 = tex->rgb + 3 * ((size_t)j0 * W + i1);
+        t01 = tex->rgb + 3 * ((size_t)j1 * W + i0); t11 = tex->rgb + 3 * ((size_t)j1 * W + i1);
+        const int wx = (int)nearbyintf(a * 256.0f), wy = (int)nearbyintf(b * 256.0f);
+        for (int k = 0; k < 3; k++) {
+            const int top = t00[k] + (((t10[k] - t00[k]) * wx + 128) >> 8);
+            const int bot = t01[k] + (((t11[k] - t01[k]) * wx + 128) >> 8);
+            c[k] = (float)(top + (((bot - top) * wy + 128) >> 8)) * OA_UNORM8;
+        }
+        out.x = c[0]; out.y = c[1]; out.z = c[2];
+        return out;
+    }
     for (int k = 0; k < 3; k++) {
-        float c00 = t00[k] / 255.0f, c10 = t10[k] / 255.0f, c01 = t01[k] / 255.0f, c11 = t11[k] / 255.0f;
+        float c00 = t00[k] * OA_UNORM8, c10 = t10[k] * OA_UNORM8, c01 = t01[k] * OA_UNORM8, c11 = t11[k] * OA_UNORM8;
         float top = c00 + a * (c10 - c00);
         float bot = c01 + a * (c11 - c01);
         c[k] = top + b * (bot - top);
     }
     out.x = c[0]; out.y = c[1]; out.z = c[2];
     return out;
+}
+
+/* texture() on n explicit coordinates (st: n x 2) -> rgb (n x 3); for the sampler fixture (tests/golden/golden_sampler.npz) */
+void oa_sample_points(const uint8_t *rgb, int w, int h, uint64_t n, const float *st, float *out) {
+    unsigned csr = _mm_getcsr();
+    apply_fp_mode();
+    const oa_texture tex = { rgb, w, h };
+    for (uint64_t i = 0; i < n; i++) {
+        const v3 c = oa_sample_albedo(&tex, st[2 * i], st[2 * i + 1]);
+        out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
+    }
+    _mm_setcsr(csr);
 }
 
 /* main, :195-235 */

@@ -455,15 +455,10 @@ __device__ __forceinline__ V3 skybox(float dx, float dy, float dz) {
 
 __device__ __forceinline__ int wrap_repeat(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
 
-// unorm8 -> float is x / 255 correctly rounded.  One Newton step on q = x * fl(1/255) with two fused
-// multiply-adds gives exactly that quotient for every x in 0..255 (tests/test_host_layer.py checks all 256
-// in exact rational arithmetic): 3 instructions instead of the 11 of a correctly rounded division, 12 times
-// per shaded pixel.  (A 256-entry __constant__ table was measured 1.6 % slower: register pressure.)
-__device__ __forceinline__ float unorm8_to_float(uint32_t x) {
-    const float r = 1.0f / 255.0f, xf = (float)x;
-    const float q = xf * r;
-    return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, xf), r, q);
-}
+// unorm8 -> float as the pinned reference executor converts it: x * fl(1/255), one multiplication (not the correctly rounded
+// quotient, from which it differs in the last bit for about half of the 256 values; tests/test_oracle_golden.py
+// test_dispatcher_ambient_directions_bit_exact pins it through ray_dispatcher.frag's noise fetch).
+__device__ __forceinline__ float unorm8_to_float(uint32_t x) { return (float)x * (1.0f / 255.0f); }
 
 // LINEAR min/mag, REPEAT, single level, RGBA8 unorm (GL 4.6 spec 8.14.2: texel
 // centres at i+0.5, weights frac(u*W-0.5)).

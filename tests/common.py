@@ -61,7 +61,6 @@ def rgb_err_255(a, b):
 DISPATCH_KEYS = ("org", "shadow_dir", "reflect_dir", "ambient_dir")
 # ambientDir goes through a LINEAR texture fetch whose weights depend on the rasteriser's
 # interpolated fragPos (not bit-reproducible); everything else must match llvmpipe bit for bit
-DISPATCH_AMBIENT_TOL = 1e-5
 
 
 def check_dispatch(got, g):
@@ -71,9 +70,10 @@ def check_dispatch(got, g):
     for k in DISPATCH_KEYS:
         assert np.all(got[k][~surface] == 0), k                      # discarded fragments keep NO_RAY
         assert np.all(g["b_" + k][~surface] == 0), k
-    for k in ("org", "shadow_dir", "reflect_dir"):
+    # all four targets bit for bit.  ambientDir too since round 2: llvmpipe converts the noise texels as x * fl(1/255), and the
+    # fixtures fetch at texel centres as src/main.rs:161-165 sets the offsets up, where LINEAR returns the texel itself
+    for k in DISPATCH_KEYS:
         assert np.array_equal(bits(got[k]), bits(g["b_" + k])), k
-    assert np.abs(got["ambient_dir"] - g["b_ambient_dir"]).max() <= DISPATCH_AMBIENT_TOL
     n = np.linalg.norm(got["ambient_dir"][surface].astype(np.float64), axis=-1)
     assert np.abs(n - 1).max() < 1e-6
 

@@ -252,6 +252,50 @@ def dispatch2():
     print("dispatch2:", int(surface.sum()), "surface pixels of", w * h, "materials", np.unique(gnm[..., 3][surface].view(np.uint32)), "->", os.path.getsize(path) / 1e6, "MB")
 
 
+def sampler():
+    """llvmpipe's RGBA8 LINEAR / REPEAT sampler, probed (round 2): ray_dispatcher.frag with `ambientDir = normalize(...)` replaced by
+    `ambientDir = random` in a temporary copy returns texture(blueNoise, fragPos * zw + xy) itself (and reflectDir the coordinate).  Stored: the images, the
+    noiseOffsetScale uniforms and llvmpipe's samples * 255 (integral: it filters in 8 bits) for power-of-two and other sizes,
+    coordinates far outside [0, 1] and exact ties of the 8-bit weight.  Pins oa_set_texture_filter_8bit (tests/test_oracle_golden.py)."""
+    import shutil
+    import tempfile
+    from oracles import REFERENCE_SHADERS
+    root = tempfile.mkdtemp(prefix="rtamd_shaders_")
+    shutil.rmtree(root)
+    shutil.copytree(REFERENCE_SHADERS, root)
+    frag = os.path.join(root, "ray_trace", "ray_dispatcher.frag")
+    text = open(frag).read()
+    statement = "ambientDir = normalize(normal + random * 2 - 1);"
+    assert text.count(statement) == 1
+    statement2 = "reflectDir = normalize(reflect(position - cameraPos, normal));"
+    assert text.count(statement2) == 1
+    open(frag, "w").write(text.replace(statement, "ambientDir = random;").replace(statement2, "reflectDir = vec3(fragPos * noiseOffsetScale.zw + noiseOffsetScale.xy, 0);"))
+    B = OracleB(shader_root=root)
+    rng = np.random.default_rng(8)
+    out = {}
+    w, h = 96, 80
+    cases = [((8, 8), [0.137, -1.29, 2.7, 3.3]), ((7, 12), [0.137, -1.29, 2.7, 3.3]), ((64, 64), [3.7, -4.2, 9.0, 8.5]), ((17, 64), [-40.3, 77.1, 3.0, 2.2]),
+             ((3, 64), [-2.0, -3.35, 0.001, 0.01]), ((1, 4), [0.0, 0.0, 1.0, 1.0]), ((17, 20), [0.5, 0.25, 1.7, 1.3]),
+             ((2, 2), [3.5 / 2, 0.25, 1.0 / 2 * 96 / 256, 0.0]), ((2, 2), [-6.5 / 2, 0.25, 1.0 / 2 * 96 / 256, 0.0])]      # the last two: weights at exact ties
+    for k, ((th, tw), nos) in enumerate(cases):
+        img = rng.integers(0, 256, (th, tw, 3), dtype=np.uint8)
+        pos = np.zeros((h, w, 3), np.float32)
+        nm = np.zeros((h, w, 4), np.float32)
+        nm[..., 0] = 1
+        both = B.dispatch(pos, nm, img, np.float32([1, 1, 1]), np.float32([2, 2, 2]), np.float32(nos))
+        r = both["ambient_dir"]
+        out[f"b_coord{k}"] = np.ascontiguousarray(both["reflect_dir"][..., :2])      # the coordinate as the shader computed it
+        k255 = np.rint(r * 255)
+        assert np.abs(r * 255 - k255).max() < 1e-3
+        out[f"image{k}"] = img; out[f"noise_offset_scale{k}"] = np.float32(nos); out[f"b_sample{k}"] = k255.astype(np.uint8)
+        out[f"b_float{k}"] = r
+    out["count"] = np.int32(len(cases)); out["size"] = np.int32([w, h]); out["renderer"] = np.array(B.renderer)
+    assert B.L.glslref_init(REFERENCE_SHADERS.encode()) == 0
+    path = os.path.join(HERE, "golden_sampler.npz")
+    np.savez_compressed(path, **out)
+    print("sampler:", len(cases), "images x", w * h, "samples ->", os.path.getsize(path) / 1e3, "kB")
+
+
 def edge():
     """Rays aimed at the edges and vertices of triangles (round 2): the decisions of intersectTriangle (:72, :78, :83) within an ulp
     of the boundary.  On the edge u + v = 1 the reference's compiler (Mesa NIR) evaluates f*du + f*dv as f*(du + dv); the fixture
@@ -408,6 +452,8 @@ if __name__ == "__main__":
         dispatch2()
     elif "--only-more-models" in sys.argv:
         main(MORE_CASES, with_extras=False)
+    elif "--only-sampler" in sys.argv:
+        sampler()
     elif "--only-edge" in sys.argv:
         edge()
     elif "--only-raycreate" in sys.argv:

@@ -116,11 +116,9 @@ for rep in range(reps):
     m = host.Model.from_arrays(tri, tri_pos.reshape(-1, 3), uv, nrm)
     m.build_bvh()
     sc = m.scene_arrays()
-    # llvmpipe filters RGBA8 in 8-bit fixed point and RETURNS 8-bit values (albedo * 255 comes out integral): against the float
-    # bilinear of the oracle that is up to 0.8/255 on a smooth image and up to 2/255 between texels of full contrast (8-bit
-    # weights on both axes), and the shader multiplies the albedo by ambient + diffuse light of up to 1.7.  The allowed colour
-    # difference is therefore the pixel's light (the oracle's colour under a white texture, at least 1) times 1/255 for the
-    # smooth image and 2.2/255 for white noise; the committed fixtures (real model textures) stay within 1/255.
+    # llvmpipe filters RGBA8 in 8-bit fixed point and returns 8-bit values: up to 2/255 from float bilinear between texels of
+    # full contrast, times up to 1.7 of light.  The oracle therefore runs with llvmpipe's filter restated
+    # (oa_set_texture_filter_8bit: 100 % of 1.8 M probed samples equal), which leaves 0.01/255 for everything else.
     tw, th = int(rng.choice([16, 32, 64])), int(rng.choice([1, 16, 64]))
     yy, xx = np.meshgrid(np.arange(th), np.arange(tw), indexing="ij")
     smooth = np.stack([128 + 90 * np.sin(2 * np.pi * (xx / tw + k / 3)) * np.cos(2 * np.pi * yy / th) for k in range(3)], axis=-1).astype(np.uint8)
@@ -128,22 +126,20 @@ for rep in range(reps):
     nr = int(rng.integers(1, 3000))
     org, d = _rays(rng, tri_pos, nr)
     d[~d.any(axis=1)] = np.float32([0, 0, 1])
-    light = A.render(sc, d, org, 1, 1, None, None)["rgba"][:, :3]
-    tol = np.maximum(1.0, np.nan_to_num(light, nan=1.0, posinf=1.0, neginf=1.0).max(axis=1))
     # one material image in both slots: llvmpipe's sampler index is per 4x4 block ("Colour is pinned")
-    for t, albedo_tol in ((smooth, 1.0), (noise, 2.2)):
+    A.set_texture_filter_8bit(1)
+    for t in (smooth, noise):
         args = (True, True, t, t)
         fused, _ = B.fused(sc, d.reshape(nr, 1, 3), org.reshape(nr, 1, 3), *args)
         a = A.render(sc, d, org, 1, 1, t, t)
-        worst = max(worst, check_colour("textured", rep, sc, org, d, a, fused, args, tol * albedo_tol))
+        worst = max(worst, check_colour("textured", rep, sc, org, d, a, fused, args, 0.01))
+    A.set_texture_filter_8bit(0)
     n_rays += 2 * nr
 print(f"textured + interpolated normals: {reps} scenes, {n_rays} rays, worst colour difference {worst:.4f}/255")
 
 # ray_dispatcher.frag on random G-buffers (tests/test_gpu_fuzz.py:test_random_gbuffers_dispatch_match_oracle), the noise texture
-# sampled at texel centres as src/main.rs:161-165 sets it up (between texels llvmpipe filters RGBA8 with 8-bit weights, the
-# oracle in float: implementation-defined in GL).  org / shadowDir / reflectDir bit for bit, NaN and inf in the same places;
-# ambientDir within 1e-3 (a coordinate a few ulps off a texel centre already changes llvmpipe's 8-bit weight, and
-# normalize(normal + random * 2 - 1) magnifies that where the sum is short; worst seen 3.3e-4).
+# sampled at texel centres (as src/main.rs:161-165 sets it up) in every other case and anywhere between texels in the rest, the
+# oracle with llvmpipe's filter restated: all four targets bit for bit, NaN and inf in the same places.
 rng = np.random.default_rng(17 + 1000 * seed)
 n_px = 0
 worst_ambient = 0.0
@@ -159,19 +155,21 @@ for rep in range(reps):
     cam = rng.uniform(-20, 20, 3).astype(np.float32)
     pos[rng.random((h, w)) < 0.02] = light
     pos[rng.random((h, w)) < 0.02] = cam
-    nos = np.float32([np.float32(rng.integers(0, nw)) / np.float32(nw), np.float32(rng.integers(0, nh)) / np.float32(nh),
-                      np.float32(w) / np.float32(nw), np.float32(h) / np.float32(nh)])
+    if rep % 2:     # texel centres, as src/main.rs:161-165 sets the uniform up
+        nos = np.float32([np.float32(rng.integers(0, nw)) / np.float32(nw), np.float32(rng.integers(0, nh)) / np.float32(nh),
+                          np.float32(w) / np.float32(nw), np.float32(h) / np.float32(nh)])
+    else:           # anywhere between texels
+        nos = np.float32([rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(0.1, 9), rng.uniform(0.1, 9)])
+    A.set_texture_filter_8bit(1)
     a = A.dispatch(pos, nm, noise, light, cam, nos)
+    A.set_texture_filter_8bit(0)
     b = B.dispatch(pos, nm, noise, light, cam, nos)
     n_px += w * h
     for k in ("org", "shadow_dir", "reflect_dir", "ambient_dir"):
         fa, fb = np.isfinite(a[k]), np.isfinite(b[k])
         if k == "ambient_dir":
-            diff = np.abs(np.where(fa & fb, a[k], 0) - np.where(fa & fb, b[k], 0)).max(initial=0.0)
-            worst_ambient = max(worst_ambient, float(diff))
-            wrong = not np.array_equal(fa, fb) or diff > 1e-3
-        else:
-            wrong = not np.array_equal(fa, fb) or not np.array_equal(bits(a[k])[fa], bits(b[k])[fa])
+            worst_ambient = max(worst_ambient, float(np.abs(np.where(fa & fb, a[k], 0) - np.where(fa & fb, b[k], 0)).max(initial=0.0)))
+        wrong = not np.array_equal(fa, fb) or not np.array_equal(bits(a[k])[fa], bits(b[k])[fa])
         if wrong:
             bad += 1
             print(f"MISMATCH dispatcher rep {rep}: {k}")

@@ -110,6 +110,19 @@ class OracleA:
     def set_flush_denormals(self, on):
         self.L.oa_set_flush_denormals(int(on))
 
+    def set_texture_filter_8bit(self, on):
+        """1: bilinear filtering as llvmpipe executes it on RGBA8 (8-bit weights, 8-bit lerps, 8-bit result); 0: float bilinear."""
+        self.L.oa_set_texture_filter_8bit(int(on))
+
+    def sample_points(self, image_rgb, st):
+        """texture() of the shaders (RGBA8, LINEAR, REPEAT) on explicit coordinates (..., 2) -> (..., 3)."""
+        img = np.ascontiguousarray(image_rgb, dtype=np.uint8)
+        c = np.ascontiguousarray(st, dtype=np.float32)
+        out = np.zeros(c.shape[:-1] + (3,), np.float32)
+        self.L.oa_sample_points(ctypes.c_void_p(img.ctypes.data), img.shape[1], img.shape[0], ctypes.c_uint64(c.size // 2),
+                                ctypes.c_void_p(c.ctypes.data), ctypes.c_void_p(out.ctypes.data))
+        return out
+
     def set_edge_sum_as_written(self, on):
         """1: the test of ray_trace.frag / ray_trace_and_shade.frag:83 as the rounded sum u + v, not as the reference's compiler factors it."""
         self.L.oa_set_edge_sum_as_written(int(on))

@@ -219,27 +219,6 @@ def test_subdivide_counts():
     assert np.allclose(np.linalg.norm(n2, axis=1), 1, atol=1e-5)
 
 
-def test_unorm8_conversion_formula_is_exact_division():
-    """rt_kernels.hip unorm8_to_float: q = x * fl(1/255); q + fma(-q, 255, x) * fl(1/255), both steps fused,
-    equals the correctly rounded x / 255 of the texture unit for all 256 inputs (exact rational arithmetic)."""
-    from fractions import Fraction
-
-    def rnd(fr):
-        if fr == 0:
-            return np.float32(0)
-        f = np.float32(float(fr))
-        cands = [np.nextafter(f, np.float32(-np.inf)), f, np.nextafter(f, np.float32(np.inf))]
-        return np.float32(min(cands, key=lambda v: (abs(Fraction(float(v)) - fr), int(np.float32(v).view(np.uint32)) & 1)))
-
-    r = np.float32(1.0) / np.float32(255.0)
-    for xi in range(256):
-        x = np.float32(xi)
-        q = x * r
-        e = rnd(Fraction(float(x)) - Fraction(float(q)) * 255)
-        q2 = rnd(Fraction(float(q)) + Fraction(float(e)) * Fraction(float(r)))
-        assert q2 == x / np.float32(255.0), xi
-
-
 def test_config1_workload_is_the_f16_fixture_at_full_size():
     """bench.py's f16_640x480 (BASELINE config 1) takes scene, textures and camera from the committed llvmpipe fixture:
     its camera at the fixture's 160x120 gives the fixture's rays bit for bit, so the 640x480 frame is the frame the
