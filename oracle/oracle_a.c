@@ -27,8 +27,14 @@
  * llvmpipe running the unmodified shader is the pinned reference (oracle B,
  * oracle/glsl_ref.c): un-fused mul/add, dot(a,b) = (a.z*b.z + a.y*b.y) + a.x*b.x,
  * normalize(v) = v * (1/sqrt(dot(v,v))), correctly rounded 1/x, min/max that
- * return the non-NaN operand.  Parity pin: tests/test_oracle_golden.py compares
- * this file with llvmpipe outputs committed under tests/golden/.
+ * return the non-NaN operand, f32 denormals flushed, `uv.x + uv.y > 1.0` evaluated as
+ * f*(du + dv) > 1.0 (the compiler's factoring, oa_tri), unorm8 texels converted as
+ * x * fl(1/255).  Texture filtering is float bilinear by default (what the library
+ * computes); oa_set_texture_filter_8bit(1) restates llvmpipe's 8-bit filter, with which
+ * textured colours and the dispatcher's noise fetch equal llvmpipe's to the last bit or
+ * 0.003/255.  Parity pin: tests/test_oracle_golden.py compares this file with llvmpipe
+ * outputs committed under tests/golden/; tests/golden/soak_oracle_vs_llvmpipe.py does the
+ * same on randomised adversarial inputs in the build container.
  *
  * Build: oracle/Makefile (gcc -O2 -ffp-contract=off -fno-fast-math).
  */
@@ -545,6 +551,11 @@ void oa_raycreate(uint32_t w, uint32_t h, const float *m, float near_, float far
  * clear value 0 = NO_RAY, main.rs:157-158).  fragPos is the quad01.vert varying at the
  * pixel centre; the blue-noise texture is an ordinary image texture (LINEAR, REPEAT).
  * materials[] is read at :36 but never used.  No threads: one memory-bound pass. */
+/* Test-only: values of the varying fragPos to use instead of the pixel centres (w*h x 2, NULL = centres).  The varying is the
+ * rasteriser's product; between texels an ulp of it can move an 8-bit filter weight, so the soak hands llvmpipe's own values in. */
+static const float *g_dispatch_frag_pos = NULL;
+void oa_set_dispatch_frag_pos(const float *xy) { g_dispatch_frag_pos = xy; }
+
 void oa_dispatch(uint32_t w, uint32_t h, const float *position, const float *normal_mat,
                  const uint8_t *noise_rgb, int nw, int nh,
                  const float *light_pos, const float *camera_pos, const float *noise_offset_scale,
@@ -566,8 +577,9 @@ void oa_dispatch(uint32_t w, uint32_t h, const float *position, const float *nor
             }
             const v3 n = { nm[0], nm[1], nm[2] };
             const v3 p = { position[3 * i], position[3 * i + 1], position[3 * i + 2] };
-            const v3 rnd = oa_sample_albedo(&noise, fx * noise_offset_scale[2] + noise_offset_scale[0],
-                                            fy * noise_offset_scale[3] + noise_offset_scale[1]);   /* :34 */
+            const float px_x = g_dispatch_frag_pos ? g_dispatch_frag_pos[2 * i] : fx, px_y = g_dispatch_frag_pos ? g_dispatch_frag_pos[2 * i + 1] : fy;
+            const v3 rnd = oa_sample_albedo(&noise, px_x * noise_offset_scale[2] + noise_offset_scale[0],
+                                            px_y * noise_offset_scale[3] + noise_offset_scale[1]);   /* :34 */
             const v3 og = oa_add(p, oa_scale(n, 0.0001f));          /* :38 */
             const v3 s = oa_normalize(oa_sub(light, p));            /* :39 */
             const v3 inc = oa_sub(p, cam);

@@ -139,7 +139,19 @@ print(f"textured + interpolated normals: {reps} scenes, {n_rays} rays, worst col
 
 # ray_dispatcher.frag on random G-buffers (tests/test_gpu_fuzz.py:test_random_gbuffers_dispatch_match_oracle), the noise texture
 # sampled at texel centres (as src/main.rs:161-165 sets it up) in every other case and anywhere between texels in the rest, the
-# oracle with llvmpipe's filter restated: all four targets bit for bit, NaN and inf in the same places.
+# oracle with llvmpipe's filter restated and on llvmpipe's own values of the varying fragPos (read back from a second draw: between
+# texels an ulp of the coordinate can move an 8-bit weight): all four targets bit for bit, NaN and inf in the same places.
+import shutil  # noqa: E402
+import tempfile  # noqa: E402
+from oracles import REFERENCE_SHADERS  # noqa: E402
+droot = tempfile.mkdtemp(prefix="rtamd_shaders_")          # a copy whose dispatcher writes the varying itself: reflectDir = fragPos
+shutil.rmtree(droot)
+shutil.copytree(REFERENCE_SHADERS, droot)
+frag = os.path.join(droot, "ray_trace", "ray_dispatcher.frag")
+text = open(frag).read()
+statement = "reflectDir = normalize(reflect(position - cameraPos, normal));"
+assert text.count(statement) == 1
+open(frag, "w").write(text.replace(statement, "reflectDir = vec3(fragPos, 0);"))
 rng = np.random.default_rng(17 + 1000 * seed)
 n_px = 0
 worst_ambient = 0.0
@@ -160,10 +172,13 @@ for rep in range(reps):
                           np.float32(w) / np.float32(nw), np.float32(h) / np.float32(nh)])
     else:           # anywhere between texels
         nos = np.float32([rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(0.1, 9), rng.uniform(0.1, 9)])
-    A.set_texture_filter_8bit(1)
-    a = A.dispatch(pos, nm, noise, light, cam, nos)
-    A.set_texture_filter_8bit(0)
     b = B.dispatch(pos, nm, noise, light, cam, nos)
+    assert B.L.glslref_init(droot.encode()) == 0
+    frag_pos = B.dispatch(pos, nm, noise, light, cam, nos)["reflect_dir"][..., :2]     # llvmpipe's own values of the varying
+    assert B.L.glslref_init(REFERENCE_SHADERS.encode()) == 0
+    A.set_texture_filter_8bit(1)
+    a = A.dispatch(pos, nm, noise, light, cam, nos, frag_pos=frag_pos)
+    A.set_texture_filter_8bit(0)
     n_px += w * h
     for k in ("org", "shadow_dir", "reflect_dir", "ambient_dir"):
         fa, fb = np.isfinite(a[k]), np.isfinite(b[k])

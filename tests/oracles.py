@@ -103,9 +103,15 @@ class OracleA:
         self.L.oa_surface_from_hits(ctypes.byref(sc), n, o.ctypes.data, d.ctypes.data, h.ctypes.data, int(has_normals), pos.ctypes.data, nm.ctypes.data)
         return pos, nm
 
-    def dispatch(self, position, normal_mat, noise_rgb, light_pos, camera_pos, noise_offset_scale):
-        """ray_dispatcher.frag over an (h, w) G-buffer (row 0 = bottom) -> dict(org, shadow_dir, reflect_dir, ambient_dir)."""
-        return _dispatch_call(self.L.oa_dispatch, position, normal_mat, noise_rgb, light_pos, camera_pos, noise_offset_scale, size_first=True)
+    def dispatch(self, position, normal_mat, noise_rgb, light_pos, camera_pos, noise_offset_scale, frag_pos=None):
+        """ray_dispatcher.frag over an (h, w) G-buffer (row 0 = bottom) -> dict(org, shadow_dir, reflect_dir, ambient_dir).
+        frag_pos (h, w, 2): values of the varying to use instead of the pixel centres (the soak hands llvmpipe's own in)."""
+        fp = None if frag_pos is None else np.ascontiguousarray(frag_pos, dtype=np.float32)
+        self.L.oa_set_dispatch_frag_pos(ctypes.c_void_p(None if fp is None else fp.ctypes.data))
+        try:
+            return _dispatch_call(self.L.oa_dispatch, position, normal_mat, noise_rgb, light_pos, camera_pos, noise_offset_scale, size_first=True)
+        finally:
+            self.L.oa_set_dispatch_frag_pos(ctypes.c_void_p(None))
 
     def set_flush_denormals(self, on):
         self.L.oa_set_flush_denormals(int(on))
