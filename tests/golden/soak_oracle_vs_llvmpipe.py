@@ -128,10 +128,11 @@ for rep in range(reps):
     d[~d.any(axis=1)] = np.float32([0, 0, 1])
     # one material image in both slots: llvmpipe's sampler index is per 4x4 block ("Colour is pinned")
     A.set_texture_filter_8bit(1)
+    has_tc, has_n = [(True, True), (True, False), (False, True)][rep % 3]       # hasTexCoords / hasNormals apart as well
     for t in (smooth, noise):
-        args = (True, True, t, t)
+        args = (has_tc, has_n, t, t)
         fused, _ = B.fused(sc, d.reshape(nr, 1, 3), org.reshape(nr, 1, 3), *args)
-        a = A.render(sc, d, org, 1, 1, t, t)
+        a = A.render(sc, d, org, int(has_tc), int(has_n), t, t)
         worst = max(worst, check_colour("textured", rep, sc, org, d, a, fused, args, 0.01))
     A.set_texture_filter_8bit(0)
     n_rays += 2 * nr
