@@ -11,7 +11,8 @@ The shader text is read from /root/reference at run time and patched in a tempor
   variant 2  additionally records stack.idx when the second traversal's loop is left: 0 for ordinary rays, 1 (loop condition
              still true) for rays through the origin.
 The slab test of a box of zeros is what correlates (400 of 400 rays in the sweep that found it): llvmpipe runs both sides of
-`if (node.is_leaf)` under masks, loads of masked-off lanes return zeros, and a ray through (0,0,0) "hits" that all-zero box.
+`if (node.is_leaf)` under masks, loads of masked-off lanes return zeros, and a ray through (0,0,0) "hits" that all-zero box --
+the likely trigger; the cause inside llvmpipe was not traced.
 Moving a 1e-3 off the origin removes the effect.  Consequence for parity: DESIGN.md section 3; the soak
 (soak_oracle_vs_llvmpipe.py) counts such pixels apart.  Usage: python tests/golden/llvmpipe_origin_artifact.py"""
 import os
