@@ -402,6 +402,11 @@ int rtamd_set_kernel_variant(rtamd_context *ctx, int variant);
  *                       (ray_trace_and_shade.frag:213-219) but consumes only `shadow_t < 1000`, which
  *                       cannot change once true, so every output is identical; only the optional
  *                       per-pixel test counters are smaller.  0 = traverse to the end (counter parity);
+ *  "texture_filter_8bit" 0/1  (default 0) how texture() filters the RGBA8 albedo and noise images.  0: bilinear in float.
+ *                       1: as the executor the parity tests are pinned to (Mesa llvmpipe) does it -- 8-bit weights, three rounded
+ *                       8-bit lerps, an 8-bit result -- reproduced bit for bit on its probed samples; with it textured colours
+ *                       are within 0.01/255 of that executor's instead of 1/255, and the dispatcher's ambient directions equal
+ *                       its own between texels too.  GL permits both; float is the more exact filter;
  *  "kernel_variant"     as rtamd_set_kernel_variant. */
 int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value);
 

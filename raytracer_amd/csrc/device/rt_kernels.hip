@@ -122,6 +122,7 @@ struct JobParams {
     uint32_t dyn_thresh;
     uint32_t leaf_thresh;
     uint32_t shadow_anyhit;       // fused mode: shadow rays stop at the first leaf that leaves t < T_HIT_LIMIT
+    uint32_t tex_filter8;         // 1: filter textures as the pinned reference executor does (8-bit weights and lerps), 0: in float
     uint32_t queue_stride;        // u32 words between queue counters
     // coherence feedback (dyn_thresh auto): {wave-uniform visits, visits, active lanes, threshold used} over a sample of the waves;
     // stats_prev = what the previous launch of this mode on this stream measured (nullptr: none yet)
@@ -461,8 +462,16 @@ __device__ __forceinline__ int wrap_repeat(int i, int n) { int m = i % n; return
 __device__ __forceinline__ float unorm8_to_float(uint32_t x) { return (float)x * (1.0f / 255.0f); }
 
 // LINEAR min/mag, REPEAT, single level, RGBA8 unorm (GL 4.6 spec 8.14.2: texel
-// centres at i+0.5, weights frac(u*W-0.5)).
-__device__ __forceinline__ V3 sample_albedo(const uint32_t *__restrict__ tex, int W, int H, float s, float t) {
+// centres at i+0.5, weights frac(u*W-0.5)).  f8 = 0: float bilinear.  f8 = 1 (option "texture_filter_8bit"): the filter as the
+// pinned reference executor (Mesa llvmpipe) runs it, bit for bit on its 69 120 probed samples (tests/golden/golden_sampler.npz):
+// coordinates wrapped before scaling unless both sizes are powers of two, weights rounded half to even to 8 bits, three 8-bit
+// lerps v0 + (((v1 - v0) * w + 128) >> 8) (x on both rows, then y), an 8-bit result.  GL allows both; float is the more exact one.
+__device__ __forceinline__ V3 sample_albedo(const uint32_t *__restrict__ tex, int W, int H, float s, float t, bool f8) {
+    if (f8 && (((W & (W - 1)) | (H & (H - 1))) != 0)) {
+        s = s - floorf(s); t = t - floorf(t);
+        if (s >= 1.0f) s = 0.99999994f;
+        if (t >= 1.0f) t = 0.99999994f;
+    }
     float u = s * (float)W - 0.5f, v = t * (float)H - 0.5f;
     float fu = floorf(u), fv = floorf(v);
     float a = u - fu, b = v - fv;
@@ -471,6 +480,18 @@ __device__ __forceinline__ V3 sample_albedo(const uint32_t *__restrict__ tex, in
     uint32_t t00 = tex[(size_t)j0 * W + i0], t10 = tex[(size_t)j0 * W + i1];
     uint32_t t01 = tex[(size_t)j1 * W + i0], t11 = tex[(size_t)j1 * W + i1];
     float c[3];
+    if (f8) {
+        const int wx = (int)__builtin_rintf(a * 256.0f), wy = (int)__builtin_rintf(b * 256.0f);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int c00 = (int)((t00 >> (8 * k)) & 255u), c10 = (int)((t10 >> (8 * k)) & 255u);
+            const int c01 = (int)((t01 >> (8 * k)) & 255u), c11 = (int)((t11 >> (8 * k)) & 255u);
+            const int top = c00 + (((c10 - c00) * wx + 128) >> 8);
+            const int bot = c01 + (((c11 - c01) * wx + 128) >> 8);
+            c[k] = unorm8_to_float((uint32_t)(top + (((bot - top) * wy + 128) >> 8)));
+        }
+        return V3{c[0], c[1], c[2]};
+    }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         float c00 = unorm8_to_float((t00 >> (8 * k)) & 255u), c10 = unorm8_to_float((t10 >> (8 * k)) & 255u);
@@ -530,10 +551,10 @@ __device__ __forceinline__ void shade_primary(const SceneDev &s, const JobParams
         for (int k = 0; k < 3; k++) { ka[k] = md.ka[k]; kd[k] = md.kd[k]; ks[k] = md.ks[k]; }
         ns = md.ns;
         const TexSlotDev ts = s.tex_slots[md.tex_slot];     // "no texture" is the slot of the 1x1 white texel
-        albedo = sample_albedo(ts.texels, ts.w, ts.h, tcx, -tcy);
+        albedo = sample_albedo(ts.texels, ts.w, ts.h, tcx, -tcy, p.tex_filter8 != 0);
     } else {
         const uint32_t m = tri.mat_idx & 1u;
-        albedo = sample_albedo(s.tex[m], s.tex_w[m], s.tex_h[m], tcx, -tcy);
+        albedo = sample_albedo(s.tex[m], s.tex_w[m], s.tex_h[m], tcx, -tcy, p.tex_filter8 != 0);
     }
     V3 sky = skybox(nx, ny, nz);
     float ndl = clamp01(dot_zyx(nx, ny, nz, sd.x, sd.y, sd.z));
@@ -1097,6 +1118,7 @@ struct DispatchParams {
     float light[3], cam[3], nos[4];
     uint32_t width, height, n;
     uint32_t rank, world, tiles_x;   // world > 1: the buffers hold this rank's tiles (compact tile-major layout), n = local tiles * 1024
+    uint32_t tex_filter8;            // as JobParams::tex_filter8, for the noise fetch
     float *out[4];             // org, shadowDir, reflectDir, ambientDir (any may be null)
 };
 
@@ -1122,7 +1144,7 @@ __global__ void __launch_bounds__(256) k_dispatch_rays(const DispatchParams p) {
         if (shard_pixel(i, p.width, p.height, p.rank, p.world, p.tiles_x, px, py) && !(nm.w == MISS)) {   // :28 discard
             const float fx = ((float)px + 0.5f) / (float)p.width, fy = ((float)py + 0.5f) / (float)p.height;   // quad01.vert:8 at the pixel centre
             const float x = sh_in[3 * tid], y = sh_in[3 * tid + 1], z = sh_in[3 * tid + 2];
-            const V3 rnd = sample_albedo(p.noise, p.noise_w, p.noise_h, fx * p.nos[2] + p.nos[0], fy * p.nos[3] + p.nos[1]);   // :34
+            const V3 rnd = sample_albedo(p.noise, p.noise_w, p.noise_h, fx * p.nos[2] + p.nos[0], fy * p.nos[3] + p.nos[1], p.tex_filter8 != 0);   // :34
             o[0][0] = x + nm.x * 0.0001f; o[0][1] = y + nm.y * 0.0001f; o[0][2] = z + nm.z * 0.0001f;                             // :38
             {   // :39 normalize(lightPos - position)
                 const float dx = p.light[0] - x, dy = p.light[1] - y, dz = p.light[2] - z;

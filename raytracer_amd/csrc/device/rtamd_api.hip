@@ -84,6 +84,7 @@ struct rtamd_context {
     uint32_t dyn_incoherent = 32;
     uint32_t leaf_thresh = 8;
     bool shadow_anyhit = true;
+    bool tex_filter8 = false;   // option "texture_filter_8bit"
     bool validate_buffers = true;     // *_device entry points check that every buffer lies inside one device allocation (check_range)
     bool launch_timing = true;        // record a start event per launch (rtamd_last_kernel_ms); the stop event is always recorded
     uint32_t queue_stride = 64;
@@ -211,6 +212,7 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     p.stats_prev = nullptr; p.stats_cur = nullptr;
     p.leaf_thresh = ctx->leaf_thresh;
     p.shadow_anyhit = ctx->shadow_anyhit ? 1u : 0u;
+    p.tex_filter8 = ctx->tex_filter8 ? 1u : 0u;
     p.queue_stride = ctx->queue_stride; p.queue_block = mode == MODE_FUSED ? ctx->queue_block_fused : ctx->queue_block_trace;
     p.spill = (uint32_t *)sl->spill.p;
     p.spill_wave_words = (uint32_t)SPILL_STACK_ENTRIES * 64u;
@@ -519,6 +521,8 @@ int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value) {
         ctx->launch_timing = value != 0;
     } else if (!std::strcmp(name, "shadow_anyhit")) {
         ctx->shadow_anyhit = value != 0;
+    } else if (!std::strcmp(name, "texture_filter_8bit")) {
+        ctx->tex_filter8 = value != 0;
     } else if (!std::strcmp(name, "num_queues")) {
         if (value < 1 || value > 32) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "num_queues must be 1..32");
         ctx->n_queues = (uint32_t)value;
@@ -811,6 +815,7 @@ int rtamd_dispatch_rays_device(rtamd_context *ctx, const rtamd_dispatch_desc *d,
     std::memcpy(p.nos, d->noise_offset_scale, sizeof p.nos);
     p.width = d->width; p.height = d->height; p.n = (uint32_t)n_entries;
     p.rank = d->tile_rank; p.world = tile_world; p.tiles_x = tiles_x;
+    p.tex_filter8 = ctx->tex_filter8 ? 1u : 0u;
     p.out[0] = o->org; p.out[1] = o->shadow_dir; p.out[2] = o->reflect_dir; p.out[3] = o->ambient_dir;
     hipLaunchKernelGGL(k_dispatch_rays, dim3((p.n + 255u) / 256u), dim3(256), 0, ctx->stream, p);
     HIP_TRY(ctx, hipGetLastError());
@@ -939,6 +944,7 @@ int rtamd_render_device_static(rtamd_context *ctx, const rtamd_frame_desc *desc,
     p.stats_prev = nullptr; p.stats_cur = nullptr;   // no coherence feedback: the re-fill threshold is the context's fixed one
     p.leaf_thresh = ctx->leaf_thresh;
     p.shadow_anyhit = ctx->shadow_anyhit ? 1u : 0u;
+    p.tex_filter8 = ctx->tex_filter8 ? 1u : 0u;
     p.spill = ptr + STATIC_QUEUE_WORDS;
     p.spill_wave_words = STATIC_SPILL_ENTRIES * 64u;
 #ifdef RTAMD_EXP_STAMPS

@@ -41,12 +41,13 @@ def _tracer_session():
 def tracer(_tracer_session):
     """The session's context with the state a test may rely on without setting it: the shader's two albedo slots hold the
     white texel (a scene without texture coordinates samples texel (0,0) of whatever the previous test left there), the
-    persistent kernel, the context's own stream.  Scene, materials and the other options are the test's business."""
+    persistent kernel, float texture filtering, the context's own stream.  Scene, materials and the other options are the test's business."""
     import numpy as np
     t = _tracer_session
     white = np.full((1, 1, 3), 255, np.uint8)
     t.set_stream(0)
     t.set_kernel_variant(0)
+    t.set_option("texture_filter_8bit", 0)
     t.upload_texture(0, white)
     t.upload_texture(1, white)
     return t

@@ -139,16 +139,21 @@ def test_random_textured_scenes_match_oracle(tracer, oracle_a):
             d[~d.any(axis=1)] = np.float32([0, 0, 1])
             tracer.upload_scene(sc)
             tracer.upload_texture(0, tex[0]); tracer.upload_texture(1, tex[1])
-            a = oracle_a.render(sc, d, org, 1, 1, tex[0], tex[1])
-            for variant in (0, 1):
-                tracer.set_kernel_variant(variant)
-                r = tracer.render(nr, 1, dir=d, org=org, has_tex_coords=1, has_normals=1)
-                assert np.array_equal(a["hit_id"], r["hit_id"]) and np.array_equal(bits(a["hit_t"]), bits(r["hit_t"])), (rep, variant)
-                assert np.array_equal(np.isfinite(a["rgba"]), np.isfinite(r["rgba"])), (rep, variant)
-                ok = np.isfinite(a["rgba"]).all(axis=1)
-                assert rgb_err_255(a["rgba"][ok], r["rgba"][ok]).max(initial=0.0) <= 0.05, (rep, variant)
+            for filter8 in (0, 1):      # float bilinear, and the reference executor's 8-bit filter (option "texture_filter_8bit")
+                oracle_a.set_texture_filter_8bit(filter8)
+                tracer.set_option("texture_filter_8bit", filter8)
+                a = oracle_a.render(sc, d, org, 1, 1, tex[0], tex[1])
+                for variant in (0, 1):
+                    tracer.set_kernel_variant(variant)
+                    r = tracer.render(nr, 1, dir=d, org=org, has_tex_coords=1, has_normals=1)
+                    assert np.array_equal(a["hit_id"], r["hit_id"]) and np.array_equal(bits(a["hit_t"]), bits(r["hit_t"])), (rep, variant)
+                    assert np.array_equal(np.isfinite(a["rgba"]), np.isfinite(r["rgba"])), (rep, variant)
+                    ok = np.isfinite(a["rgba"]).all(axis=1)
+                    assert rgb_err_255(a["rgba"][ok], r["rgba"][ok]).max(initial=0.0) <= 0.05, (rep, variant, filter8)
     finally:
         tracer.set_kernel_variant(0)
+        tracer.set_option("texture_filter_8bit", 0)
+        oracle_a.set_texture_filter_8bit(0)
 
 
 def test_random_gbuffers_dispatch_match_oracle(tracer, oracle_a):
@@ -172,9 +177,16 @@ def test_random_gbuffers_dispatch_match_oracle(tracer, oracle_a):
         pos[rng.random((h, w)) < 0.02] = cam                                    # position - cameraPos = 0
         nos = np.float32([rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(0.1, 9), rng.uniform(0.1, 9)])
         tracer.upload_noise_texture(noise)
-        r = tracer.dispatch_rays(pos, nm, light, cam, nos)
-        a = oracle_a.dispatch(pos, nm, noise, light, cam, nos)
-        for k in ("org", "shadow_dir", "reflect_dir", "ambient_dir"):
-            fa, fr = np.isfinite(a[k]), np.isfinite(r[k])
-            assert np.array_equal(fa, fr), (rep, k)
-            assert np.array_equal(bits(a[k])[fa], bits(r[k])[fa]), (rep, k, w, h)
+        for filter8 in (0, 1):          # float bilinear, and the reference executor's 8-bit filter (option "texture_filter_8bit")
+            tracer.set_option("texture_filter_8bit", filter8)
+            oracle_a.set_texture_filter_8bit(filter8)
+            try:
+                r = tracer.dispatch_rays(pos, nm, light, cam, nos)
+                a = oracle_a.dispatch(pos, nm, noise, light, cam, nos)
+            finally:
+                tracer.set_option("texture_filter_8bit", 0)
+                oracle_a.set_texture_filter_8bit(0)
+            for k in ("org", "shadow_dir", "reflect_dir", "ambient_dir"):
+                fa, fr = np.isfinite(a[k]), np.isfinite(r[k])
+                assert np.array_equal(fa, fr), (rep, k, filter8)
+                assert np.array_equal(bits(a[k])[fa], bits(r[k])[fa]), (rep, k, w, h, filter8)

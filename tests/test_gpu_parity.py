@@ -38,6 +38,31 @@ def test_trace_special_values(tracer):
     assert np.array_equal(bits(hits), bits(g["b_trace"].reshape(-1, 4)))
 
 
+@pytest.mark.parametrize("name", ["f16", "testobj", "atrium"])
+def test_textured_colour_with_the_reference_executors_filter(tracer, name):
+    """Option "texture_filter_8bit": the kernels filter as llvmpipe does (restated bit for bit on its probed samples,
+    tests/test_oracle_golden.py), and the textured fixtures then agree with llvmpipe to 0.02/255 on every pixel instead of
+    0.9/255 -- the library's texture-coordinate interpolation, v flip, wrapping and slot choice are the reference's."""
+    from common import atrium_golden
+    if name == "atrium":
+        g = atrium_golden()
+        tracer.upload_scene(g["scene"])
+        tracer.upload_texture(0, g["tex0"]); tracer.upload_texture(1, g["tex1"])
+        w, h, flags, want = g["w"], g["h"], (1, 1), g["b_fused_uniform"]
+    else:
+        g = load_golden(name)
+        _upload(tracer, g)
+        h, w = g["dir"].shape[:2]
+        flags, want = (int(g["has_tex_coords"]), int(g["has_normals"])), reference_colour(g)
+    tracer.set_option("texture_filter_8bit", 1)
+    try:
+        r = tracer.render(w, h, dir=g["dir"], org=g["org"], has_tex_coords=flags[0], has_normals=flags[1], want=("rgba",))
+    finally:
+        tracer.set_option("texture_filter_8bit", 0)
+    err = rgb_err_255(r["rgba"].reshape(-1, 4), want.reshape(-1, 4))
+    assert err.max() <= 0.02, float(err.max())
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 def test_rays_on_triangle_edges(tracer, variant):
     """golden_edge: the decisions of intersectTriangle within an ulp of an edge or a vertex, against llvmpipe's records and
