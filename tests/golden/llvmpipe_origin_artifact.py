@@ -59,12 +59,20 @@ def main():
     print(f"{plain.renderer}\nconstant shadow origin P = {p}, ray_trace.frag from P towards the sun: t = {t_occluder}")
     const_origin = ("org + dir * t + normal * 0.0001,",
                     f"vec3(uintBitsToFloat({p.view(np.uint32)[0]}u), uintBitsToFloat({p.view(np.uint32)[1]}u), uintBitsToFloat({p.view(np.uint32)[2]}u)),")
-    v1 = OracleB(shader_root=patched([const_origin, ("fragCol = vec4(ambient + diffuse + specular, 1);", "fragCol = vec4(shadow_t);")]))
-    v2 = OracleB(shader_root=patched([
+    v1 = patched([const_origin, ("fragCol = vec4(ambient + diffuse + specular, 1);", "fragCol = vec4(shadow_t);")])
+    v2 = patched([
         const_origin,
         ("float intersectAABB(", "uint idx_at_exit = 77;\nfloat intersectAABB("),
         ("            }\n        }\n    }\n}", "            }\n        }\n    }\n    idx_at_exit = stack.idx;\n}"),
-        ("fragCol = vec4(ambient + diffuse + specular, 1);", "fragCol = vec4(shadow_t, float(idx_at_exit), 0, 0);")]))
+        ("fragCol = vec4(ambient + diffuse + specular, 1);", "fragCol = vec4(shadow_t, float(idx_at_exit), 0, 0);")])
+
+    def fused_with(root, o):        # the harness keeps ONE shader root per process: switch it for the call
+        assert plain.L.glslref_init(root.encode()) == 0
+        try:
+            return plain.fused(scene, d.reshape(n, 1, 3), o.reshape(n, 1, 3), False, False, None, None)[0].reshape(-1, 4)
+        finally:
+            assert plain.L.glslref_init(REFERENCE_SHADERS.encode()) == 0
+
     n = 2000
     d = (rng.choice([-1, 1], (n, 3)) * 2.0 ** rng.integers(-3, 1, (n, 3))).astype(np.float32)     # powers of two: org = -s * d is exact
     org = (-(2.0 ** rng.integers(1, 4, (n, 1))) * d).astype(np.float32)
@@ -73,8 +81,8 @@ def main():
     failed = False
     for label, o, expect_artefact in (("primary rays through (0,0,0)", org, True), ("the same rays, origin moved 1e-3", shifted, False)):
         hit = plain.trace(scene, d.reshape(n, 1, 3), o.reshape(n, 1, 3))[0].reshape(-1, 4)[:, 0] < 1000     # pixels that reach the shading branch
-        s1 = v1.fused(scene, d.reshape(n, 1, 3), o.reshape(n, 1, 3), False, False, None, None)[0].reshape(-1, 4)[hit, 0]
-        s2 = v2.fused(scene, d.reshape(n, 1, 3), o.reshape(n, 1, 3), False, False, None, None)[0].reshape(-1, 4)[hit]
+        s1 = fused_with(v1, o)[hit, 0]
+        s2 = fused_with(v2, o)[hit]
         found = int((s1 == t_occluder).sum())
         nothing = int((s1 == 1000000).sum())
         print(f"{label}: {int(hit.sum())} shaded pixels; second traversal from P: {found} find t = {t_occluder}, {nothing} find nothing; "

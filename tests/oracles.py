@@ -208,7 +208,8 @@ class OracleA:
 
 
 class OracleB:
-    """llvmpipe; arrays are (h, w, c) with row 0 = bottom row (GL convention)."""
+    """llvmpipe; arrays are (h, w, c) with row 0 = bottom row (GL convention).  The harness keeps ONE shader root per process
+    (glslref_init): a second instance with another root redirects the first; switch with L.glslref_init(root) around a call."""
 
     def __init__(self, shader_root=REFERENCE_SHADERS):
         if not os.path.isdir(shader_root):
