@@ -3,7 +3,7 @@
 fixtures.  The adversarial scene / ray generators of tests/test_gpu_fuzz.py (exact ties, flat boxes, duplicated and degenerate
 triangles, 1e-30 .. 1e6 coordinates, denormals, zero direction components, origins on box faces, NO_RAY entries) feed the
 UNMODIFIED ray_trace.frag and ray_trace_and_shade.frag on Mesa llvmpipe and oracle/oracle_a.c: hit records must agree bit for
-bit, colours within 1/255.
+bit, colours within 0.01/255 (textured scenes with llvmpipe's 8-bit texture filter restated in the oracle).
 
 One class of colour differences is the executor's, not the shader's, and is counted apart ("llvmpipe and
 rays through the coordinate origin"; tests/golden/llvmpipe_origin_artifact.py shows it without any oracle): when a primary ray
@@ -46,6 +46,7 @@ A, B = OracleA(), OracleB()
 A.set_flush_denormals(1)
 print("reference:", B.renderer)
 bad = n_origin = n_group = 0
+worst_unshadowed = 0.0      # over pixels the oracle does not put in shadow: the origin artefact cannot hide below the tolerance there
 def check_colour(kind, rep, sc, org, d2, a, fused, args, tol=1.0):
     """Shared by the plain and the textured part: colour within tol/255 (a number or one per pixel), the origin artefact counted apart."""
     global bad, n_origin, n_group
@@ -67,6 +68,8 @@ def check_colour(kind, rep, sc, org, d2, a, fused, args, tol=1.0):
         bad += 1
         k = int((err - tol).argmax())
         print(f"MISMATCH colour {kind} rep {rep}: {err[k]:.3f}/255 (allowed {tol[k]:.3f}) at ray {k}: oracle {a['rgba'][k]} reference {fused[k]} org {org[k]} dir {d2[k]}")
+    global worst_unshadowed
+    worst_unshadowed = max(worst_unshadowed, float(err[a["shadow"] != 1].max(initial=0.0)))
     return float(err.max(initial=0.0))
 
 
@@ -91,7 +94,7 @@ for kind in ("grid", "dup", "degenerate", "scales", "soup"):
         fused, _ = B.fused(sc, d2.reshape(n, 1, 3), o3, False, False, None, None)
         a = A.render(sc, d2, org, 0, 0)
         fused = fused.reshape(-1, 4)
-        worst = max(worst, check_colour(kind, rep, sc, org, d2, a, fused, (False, False, None, None)))
+        worst = max(worst, check_colour(kind, rep, sc, org, d2, a, fused, (False, False, None, None), 0.01))
         n_rays += n
         n_hit += int((ref[:, 0] < 1e30).sum())
     print(f"{kind}: {reps} scenes, {n_rays} rays, {n_hit} hits, worst colour difference {worst:.4f}/255")
@@ -234,6 +237,7 @@ assert B.L.glslref_init(REFERENCE_SHADERS.encode()) == 0
 print(f"(from correctly rounded pixel centres instead of llvmpipe's fragPos: {n_off} pixels differ, by at most {worst_centre:.2e})")
 print(f"ray_create: {reps} cameras, {n_px} pixels")
 
+print(f"worst colour difference over all pixels that are not in shadow (sky, lit surfaces; every part above): {worst_unshadowed:.4f}/255")
 print(f"llvmpipe origin artefact (not counted): {n_origin} pixels whose own ray passes through (0,0,0), {n_group} pixels that agree when drawn alone")
 print("FAILED" if bad else "ok", bad)
 sys.exit(1 if bad else 0)
