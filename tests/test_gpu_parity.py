@@ -115,8 +115,9 @@ def test_fused_render_matches_reference_shader(tracer, oracle_a, name, variant, 
     assert np.array_equal(hit, want_trace[:, 0] < 1000.0)
     assert np.array_equal(r["hit_id"][hit], bits(want_trace[:, 3])[hit])
     assert np.array_equal(bits(r["hit_t"])[hit], bits(want_trace[:, 0])[hit])
-    # colour: <= 1/255 against the reference shader on llvmpipe on EVERY pixel, and against oracle A
-    assert rgb_err_255(r["rgba"], reference_colour(g)).max() <= 1.0
+    # colour against the reference shader on llvmpipe on EVERY pixel: 0.06/255 without textures (the GPU's pow), 1/255 with
+    # them (llvmpipe filters in 8 bits; 0.02/255 with option "texture_filter_8bit", tested below), and against oracle A
+    assert rgb_err_255(r["rgba"], reference_colour(g)).max() <= (1.0 if int(g["has_tex_coords"]) else 0.06)
     assert rgb_err_255(r["rgba"], a["rgba"]).max() <= 0.05
     assert np.all(r["rgba"][:, 3] == 1.0)
 
