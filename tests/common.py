@@ -136,3 +136,19 @@ def check_raycreate(generate):
         got = np.asarray(generate(w, h, g[f"inv_proj_view{k}"], near, far), np.float32).reshape(-1, 3)
         assert np.abs(got - want).max() <= (2e-5 if k < 3 else 3e-4), (k, float(np.abs(got - want).max()))
         assert (bits(got) == bits(want)).mean() >= 0.95, k
+
+
+def check_fullsize_rows(name, scene, hits, w, h):
+    """hits: the (t, u, v, idx-bits) records of the whole frame of bench.py workload `name`, row 0 = bottom, against the digests of
+    ray_trace.frag on llvmpipe AT THE CONFIG'S STATED SIZE (tests/golden/golden_fullsize.npz, make_golden.py:fullsize): every
+    pixel row must hash to llvmpipe's row, i.e. the full frame is the reference's bit for bit."""
+    import hashlib
+    g = load_golden("fullsize")
+    assert tuple(int(x) for x in g[f"{name}_size"]) == (w, h)
+    digest = hashlib.sha256(b"".join(np.ascontiguousarray(scene[k]).tobytes() for k in ("nodes", "triangles", "positions"))).hexdigest()
+    assert digest == str(g[f"{name}_scene_sha256"]), "the rebuilt scene differs from the one the fixture was made with"
+    rec = np.ascontiguousarray(hits, dtype=np.float32).reshape(h, w, 4)
+    assert np.array_equal((rec[..., 0] < 1e30).sum(axis=1), g[f"{name}_row_hits"]), "hit counts per row"
+    rows = np.stack([np.frombuffer(hashlib.sha256(rec[y].tobytes()).digest(), np.uint8) for y in range(h)])
+    wrong = np.where((rows != g[f"{name}_row_sha256"]).any(axis=1))[0]
+    assert len(wrong) == 0, f"{len(wrong)} of {h} rows differ from llvmpipe's, first row {wrong[0]}"

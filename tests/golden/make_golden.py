@@ -28,6 +28,7 @@ The fixtures are data only.  Usage:  python tests/golden/make_golden.py [--only-
 import math
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -252,6 +253,35 @@ def dispatch2():
     print("dispatch2:", int(surface.sum()), "surface pixels of", w * h, "materials", np.unique(gnm[..., 3][surface].view(np.uint32)), "->", os.path.getsize(path) / 1e6, "MB")
 
 
+def fullsize(names=("f16_640x480", "bunny_1080p", "atrium_1080p", "soup_10m_4k")):
+    """BASELINE configs 1-4 AT THEIR STATED SIZES (round 2): ray_trace.frag on llvmpipe over the primary rays of bench.py's workloads,
+    kept as one SHA-256 per pixel row of the (t, u, v, idx) records (a full frame of records is 33-133 MB; hit records are bit-exact, so
+    a digest loses nothing) plus the number of hits per row and a digest of the rebuilt scene.  tests/test_gpu_api.py compares the
+    library's whole frame with these row by row."""
+    import hashlib
+    sys.path.insert(0, REPO)
+    import bench
+    B = OracleB()
+    path = os.path.join(HERE, "golden_fullsize.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    for name in names:
+        model, camera, w, h, _ = bench.build_workload(name)
+        sc = model.scene_arrays()
+        digest = hashlib.sha256(b"".join(np.ascontiguousarray(sc[k]).tobytes() for k in ("nodes", "triangles", "positions"))).hexdigest()
+        dirs, orgs = camera.primary_rays(w, h)
+        t0 = time.time()
+        hits, _ = B.trace(sc, dirs.reshape(h, w, 3), orgs.reshape(h, w, 3))
+        hits = np.ascontiguousarray(hits.reshape(h, w, 4), dtype=np.float32)
+        out[f"{name}_size"] = np.int32([w, h])
+        out[f"{name}_scene_sha256"] = np.array(digest)
+        out[f"{name}_row_sha256"] = np.stack([np.frombuffer(hashlib.sha256(hits[y].tobytes()).digest(), np.uint8) for y in range(h)])
+        out[f"{name}_row_hits"] = (hits[..., 0] < 1e30).sum(axis=1).astype(np.int32)
+        print(f"fullsize {name}: {w}x{h}, {int((hits[..., 0] < 1e30).sum())} hits, llvmpipe {time.time() - t0:.1f} s")
+    out["renderer"] = np.array(B.renderer)
+    np.savez_compressed(path, **out)
+    print("fullsize ->", os.path.getsize(path) / 1e3, "kB")
+
+
 def sampler():
     """llvmpipe's RGBA8 LINEAR / REPEAT sampler, probed (round 2): ray_dispatcher.frag with `ambientDir = normalize(...)` replaced by
     `ambientDir = random` in a temporary copy returns texture(blueNoise, fragPos * zw + xy) itself (and reflectDir the coordinate).  Stored: the images, the
@@ -452,6 +482,9 @@ if __name__ == "__main__":
         dispatch2()
     elif "--only-more-models" in sys.argv:
         main(MORE_CASES, with_extras=False)
+    elif "--only-fullsize" in sys.argv:
+        extra = [a for a in sys.argv[1:] if not a.startswith("--")]
+        fullsize(tuple(extra)) if extra else fullsize()
     elif "--only-sampler" in sys.argv:
         sampler()
     elif "--only-edge" in sys.argv:

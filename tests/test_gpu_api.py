@@ -463,12 +463,33 @@ def test_two_contexts_render_concurrently(tracer, atrium):
         other.close()
 
 
+@pytest.mark.parametrize("name", ["f16_640x480", "bunny_1080p", "atrium_1080p"])
+def test_full_size_hit_records_equal_llvmpipe(tracer, name):
+    """BASELINE configs 1-3 at their stated sizes against the reference itself: the hit records of the whole frame (bench.py's
+    workload, both kernel variants) hash, pixel row by pixel row, to what ray_trace.frag gave on llvmpipe (golden_fullsize.npz) --
+    bit-exact parity on all 307 200 / 2 073 600 pixels, not on a sample of rows."""
+    import bench
+    from common import check_fullsize_rows
+    model, camera, w, h, _ = bench.build_workload(name)
+    sc = model.scene_arrays()
+    tracer.upload_scene(sc)
+    dirs, orgs = camera.primary_rays(w, h)
+    for variant in (0, 1):
+        tracer.set_kernel_variant(variant)
+        try:
+            hits = tracer.trace(orgs.reshape(-1, 3), dirs.reshape(-1, 3))
+        finally:
+            tracer.set_kernel_variant(0)
+        check_fullsize_rows(name, sc, hits, w, h)
+
+
 @pytest.mark.timeout(900)
 def test_full_size_soup_10m_4k(tracer, oracle_a):
     """BASELINE config 4 at full size: 10 000 000-triangle soup (seed 1, no uvs / normals), 3840x2160,
     camera at (0, 0, -250) looking +z, fovy 60.  Size-independent properties: the 8 interleaved tile
     shards of the multi-GPU split re-assemble to the single-GPU frame bit for bit, both kernel variants
-    agree, and sampled pixel rows equal the CPU oracle (hit records bit-exact, colour <= 0.05/255)."""
+    agree, sampled pixel rows equal the CPU oracle (hit records bit-exact, colour <= 0.05/255), and the hit records of the whole
+    frame equal ray_trace.frag's on llvmpipe (row digests)."""
     tri, pos, cam = scenes.triangle_soup(10_000_000, seed=1)
     m = host.Model.from_arrays(tri, pos)
     del tri, pos
@@ -505,6 +526,11 @@ def test_full_size_soup_10m_4k(tracer, oracle_a):
     a = oracle_a.render(sc, dirs.reshape(-1, 3)[sel], orgs.reshape(-1, 3)[sel], 0, 0, nthreads=16)
     assert np.array_equal(a["hit_id"], full["hit_id"][sel]) and np.array_equal(bits(a["hit_t"]), bits(full["hit_t"][sel]))
     assert rgb_err_255(a["rgba"], full["rgba"][sel]).max() <= 0.05
+    # and against the reference itself: every row of the 8.3 M hit records hashes to ray_trace.frag's on llvmpipe (golden_fullsize.npz)
+    from common import check_fullsize_rows
+    hits = tracer.trace(orgs.reshape(-1, 3), dirs.reshape(-1, 3))
+    check_fullsize_rows("soup_10m_4k", sc, hits, W, H)
+    assert np.array_equal(bits(hits[:, 0])[hit], bits(full["hit_t"])[hit]) and np.array_equal(bits(hits[:, 3])[hit], full["hit_id"][hit])
 
 
 def test_coherence_feedback_separates_camera_rays_from_soup(tracer, atrium):
