@@ -152,3 +152,22 @@ def check_fullsize_rows(name, scene, hits, w, h):
     rows = np.stack([np.frombuffer(hashlib.sha256(rec[y].tobytes()).digest(), np.uint8) for y in range(h)])
     wrong = np.where((rows != g[f"{name}_row_sha256"]).any(axis=1))[0]
     assert len(wrong) == 0, f"{len(wrong)} of {h} rows differ from llvmpipe's, first row {wrong[0]}"
+
+
+def block_means(rgb, block=16):
+    """(h, w, 3) -> (ceil(h / block), ceil(w / block), 3): the mean over each block's pixels, accumulated in float64."""
+    h, w = rgb.shape[:2]
+    ys, xs = np.arange(h) // block, np.arange(w) // block
+    nb_y, nb_x = ys[-1] + 1, xs[-1] + 1
+    flat = (ys[:, None] * nb_x + xs[None, :]).reshape(-1)
+    out = np.stack([np.bincount(flat, weights=rgb[..., c].reshape(-1).astype(np.float64), minlength=nb_y * nb_x) for c in range(3)], axis=-1)
+    return (out / np.bincount(flat, minlength=nb_y * nb_x)[:, None]).reshape(nb_y, nb_x, 3)
+
+
+def check_fullsize_colour(name, rgba, w, h, tol_255):
+    """rgba: the fused shader's whole frame of bench.py workload `name` (row 0 = bottom) against llvmpipe's frame at the config's
+    stated size, kept as the mean RGB of every 16 x 16 pixel block (golden_fullsize.npz): every block within tol_255 / 255."""
+    g = load_golden("fullsize")
+    got = block_means(np.asarray(rgba, np.float32).reshape(h, w, -1)[..., :3])
+    err = np.abs(got - g[f"{name}_block_mean_rgb"]).max() * 255
+    assert err <= tol_255, f"block means differ by {err:.4f}/255"

@@ -37,7 +37,7 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 
-from common import bits  # noqa: E402
+from common import bits, block_means  # noqa: E402
 from oracles import OracleA, OracleB  # noqa: E402
 from raytracer_amd import host  # noqa: E402
 
@@ -256,8 +256,8 @@ def dispatch2():
 def fullsize(names=("f16_640x480", "bunny_1080p", "atrium_1080p", "soup_10m_4k")):
     """BASELINE configs 1-4 AT THEIR STATED SIZES (round 2): ray_trace.frag on llvmpipe over the primary rays of bench.py's workloads,
     kept as one SHA-256 per pixel row of the (t, u, v, idx) records (a full frame of records is 33-133 MB; hit records are bit-exact, so
-    a digest loses nothing) plus the number of hits per row and a digest of the rebuilt scene.  tests/test_gpu_api.py compares the
-    library's whole frame with these row by row."""
+    a digest loses nothing) plus the number of hits per row and a digest of the rebuilt scene; for the colour of the fused shader, which
+    is not bit-exact, the mean RGB of every 16 x 16 pixel block.  tests/test_gpu_api.py compares the library's whole frames with these."""
     import hashlib
     sys.path.insert(0, REPO)
     import bench
@@ -265,7 +265,7 @@ def fullsize(names=("f16_640x480", "bunny_1080p", "atrium_1080p", "soup_10m_4k")
     path = os.path.join(HERE, "golden_fullsize.npz")
     out = dict(np.load(path)) if os.path.exists(path) else {}
     for name in names:
-        model, camera, w, h, _ = bench.build_workload(name)
+        model, camera, w, h, tex = bench.build_workload(name)
         sc = model.scene_arrays()
         digest = hashlib.sha256(b"".join(np.ascontiguousarray(sc[k]).tobytes() for k in ("nodes", "triangles", "positions"))).hexdigest()
         dirs, orgs = camera.primary_rays(w, h)
@@ -276,6 +276,12 @@ def fullsize(names=("f16_640x480", "bunny_1080p", "atrium_1080p", "soup_10m_4k")
         out[f"{name}_scene_sha256"] = np.array(digest)
         out[f"{name}_row_sha256"] = np.stack([np.frombuffer(hashlib.sha256(hits[y].tobytes()).digest(), np.uint8) for y in range(h)])
         out[f"{name}_row_hits"] = (hits[..., 0] < 1e30).sum(axis=1).astype(np.int32)
+        # colour is not bit-exact, so no digest: the mean of the fused shader's RGB over every 16 x 16 pixel block instead
+        # (float64 sums; each material's image bound to both slots, see fused_uniform)
+        white = np.full((1, 1, 3), 255, np.uint8)
+        tex0, tex1 = (tex[0] if tex[0] is not None else white), (tex[1] if tex[1] is not None else white)
+        colour = fused_uniform(B, sc, dirs.reshape(h, w, 3), orgs.reshape(h, w, 3), model.has_tex_coords(), model.has_normals(), tex0, tex1, hits)
+        out[f"{name}_block_mean_rgb"] = block_means(colour[..., :3]).astype(np.float32)
         print(f"fullsize {name}: {w}x{h}, {int((hits[..., 0] < 1e30).sum())} hits, llvmpipe {time.time() - t0:.1f} s")
     out["renderer"] = np.array(B.renderer)
     np.savez_compressed(path, **out)

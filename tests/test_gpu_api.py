@@ -467,20 +467,30 @@ def test_two_contexts_render_concurrently(tracer, atrium):
 def test_full_size_hit_records_equal_llvmpipe(tracer, name):
     """BASELINE configs 1-3 at their stated sizes against the reference itself: the hit records of the whole frame (bench.py's
     workload, both kernel variants) hash, pixel row by pixel row, to what ray_trace.frag gave on llvmpipe (golden_fullsize.npz) --
-    bit-exact parity on all 307 200 / 2 073 600 pixels, not on a sample of rows."""
+    bit-exact parity on all 307 200 / 2 073 600 pixels, not on a sample of rows -- and the fused shader's colours agree with
+    ray_trace_and_shade.frag's on llvmpipe in every 16 x 16 block."""
     import bench
-    from common import check_fullsize_rows
-    model, camera, w, h, _ = bench.build_workload(name)
+    from common import check_fullsize_colour, check_fullsize_rows
+    model, camera, w, h, tex = bench.build_workload(name)
     sc = model.scene_arrays()
     tracer.upload_scene(sc)
+    for slot, t in enumerate(tex):
+        if t is not None:
+            tracer.upload_texture(slot, t)
     dirs, orgs = camera.primary_rays(w, h)
     for variant in (0, 1):
         tracer.set_kernel_variant(variant)
+        tracer.set_option("texture_filter_8bit", 1)
         try:
             hits = tracer.trace(orgs.reshape(-1, 3), dirs.reshape(-1, 3))
+            r = tracer.render(w, h, dir=dirs, org=orgs, has_tex_coords=int(model.has_tex_coords()), has_normals=int(model.has_normals()), want=("rgba",))
         finally:
             tracer.set_kernel_variant(0)
+            tracer.set_option("texture_filter_8bit", 0)
         check_fullsize_rows(name, sc, hits, w, h)
+        # the fused shader's colour of the same frame, with the reference executor's texture filter: the mean RGB of every
+        # 16 x 16 pixel block within 0.03/255 of llvmpipe's (per pixel the GPU's pow is good to 0.05/255)
+        check_fullsize_colour(name, r["rgba"], w, h, 0.03)
 
 
 @pytest.mark.timeout(900)
@@ -530,6 +540,8 @@ def test_full_size_soup_10m_4k(tracer, oracle_a):
     from common import check_fullsize_rows
     hits = tracer.trace(orgs.reshape(-1, 3), dirs.reshape(-1, 3))
     check_fullsize_rows("soup_10m_4k", sc, hits, W, H)
+    from common import check_fullsize_colour
+    check_fullsize_colour("soup_10m_4k", full["rgba"], W, H, 0.03)     # the fused shader's colour: 16 x 16 block means vs llvmpipe
     assert np.array_equal(bits(hits[:, 0])[hit], bits(full["hit_t"])[hit]) and np.array_equal(bits(hits[:, 3])[hit], full["hit_id"][hit])
 
 
