@@ -171,3 +171,15 @@ def check_fullsize_colour(name, rgba, w, h, tol_255):
     got = block_means(np.asarray(rgba, np.float32).reshape(h, w, -1)[..., :3])
     err = np.abs(got - g[f"{name}_block_mean_rgb"]).max() * 255
     assert err <= tol_255, f"block means differ by {err:.4f}/255"
+
+
+def group_digests(a, rows=16):
+    """(h, w, c) float32 -> one SHA-256 per group of `rows` pixel rows (tests/golden/make_golden.py:split4k)."""
+    import hashlib
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return np.stack([np.frombuffer(hashlib.sha256(a[y:y + rows].tobytes()).digest(), np.uint8) for y in range(0, a.shape[0], rows)])
+
+
+def check_group_digests(g, key, a):
+    wrong = np.where((group_digests(a) != g[key]).any(axis=1))[0]
+    assert len(wrong) == 0, f"{key}: {len(wrong)} of {len(g[key])} row groups differ from llvmpipe's, first group {wrong[0]} (rows {16 * wrong[0]}..)"

@@ -37,7 +37,7 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 
-from common import bits, block_means  # noqa: E402
+from common import bits, block_means, group_digests  # noqa: E402
 from oracles import OracleA, OracleB  # noqa: E402
 from raytracer_amd import host  # noqa: E402
 
@@ -288,6 +288,45 @@ def fullsize(names=("f16_640x480", "bunny_1080p", "atrium_1080p", "soup_10m_4k")
     print("fullsize ->", os.path.getsize(path) / 1e3, "kB")
 
 
+def split4k():
+    """The split pipeline of src/main.rs:156-203 at config 5's frame size (round 2): the atrium at 3840 x 2160 -- primary hit records
+    (ray_trace.frag on llvmpipe), the G-buffer made from them (oracle A's restatement of the rasteriser pass, which the reference
+    fills by rasterising), ray_dispatcher.frag on llvmpipe with the 128 x 128 crop of the reference's blue-noise image at a texel-grid
+    offset and scale (frame / image size, as main.rs:161-165), then ray_trace.frag three times on (org, shadowDir | reflectDir |
+    ambientDir).  Kept: one SHA-256 per 16 pixel rows of each of the nine buffers.  tests/test_gpu_api.py runs the same chain through
+    the library."""
+    sys.path.insert(0, REPO)
+    import bench
+    from oracles import OracleA
+    A, B = OracleA(), OracleB()
+    model, camera, _, _, _ = bench.build_workload("atrium_1080p")
+    w, h = 3840, 2160
+    sc = model.scene_arrays()
+    dirs, orgs = camera.primary_rays(w, h)
+    dirs, orgs = dirs.reshape(h, w, 3), orgs.reshape(h, w, 3)
+    out = {"size": np.int32([w, h])}
+    primary, _ = B.trace(sc, dirs, orgs)
+    out["primary"] = group_digests(primary.reshape(h, w, 4))
+    pos, nm = A.surface_from_hits(sc, orgs.reshape(-1, 3), dirs.reshape(-1, 3), primary.reshape(-1, 4), 1)
+    gpos, gnm = pos.reshape(h, w, 3), nm.reshape(h, w, 4)
+    out["position"] = group_digests(gpos); out["normal_mat"] = group_digests(gnm)
+    noise = np.load(os.path.join(HERE, "golden_dispatch2.npz"))["noise"]
+    light = np.array([4.0, 9.0, -3.0], np.float32)
+    cam_pos = np.asarray(camera.position, np.float32)
+    nos = np.array([37 / 128, 101 / 128, w / 128, h / 128], np.float32)
+    d = B.dispatch(gpos, gnm, noise, light, cam_pos, nos)
+    for k in ("org", "shadow_dir", "reflect_dir", "ambient_dir"):
+        out[k] = group_digests(d[k])
+    for k in ("shadow_dir", "reflect_dir", "ambient_dir"):
+        hits, _ = B.trace(sc, d[k], d["org"])
+        out["hits_" + k] = group_digests(hits.reshape(h, w, 4))
+        out["n_hits_" + k] = np.int64((hits.reshape(-1, 4)[:, 0] < 1e30).sum())
+    out["light_pos"] = light; out["camera_pos"] = cam_pos; out["noise_offset_scale"] = nos; out["renderer"] = np.array(B.renderer)
+    path = os.path.join(HERE, "golden_split4k.npz")
+    np.savez_compressed(path, **out)
+    print("split4k:", {k: int(out[k]) for k in out if k.startswith("n_hits")}, "->", os.path.getsize(path) / 1e3, "kB")
+
+
 def sampler():
     """llvmpipe's RGBA8 LINEAR / REPEAT sampler, probed (round 2): ray_dispatcher.frag with `ambientDir = normalize(...)` replaced by
     `ambientDir = random` in a temporary copy returns texture(blueNoise, fragPos * zw + xy) itself (and reflectDir the coordinate).  Stored: the images, the
@@ -491,6 +530,8 @@ if __name__ == "__main__":
     elif "--only-fullsize" in sys.argv:
         extra = [a for a in sys.argv[1:] if not a.startswith("--")]
         fullsize(tuple(extra)) if extra else fullsize()
+    elif "--only-split4k" in sys.argv:
+        split4k()
     elif "--only-sampler" in sys.argv:
         sampler()
     elif "--only-edge" in sys.argv:

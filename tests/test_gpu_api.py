@@ -493,6 +493,40 @@ def test_full_size_hit_records_equal_llvmpipe(tracer, name):
         check_fullsize_colour(name, r["rgba"], w, h, 0.03)
 
 
+def test_split_pipeline_4k_equals_llvmpipe(tracer):
+    """The split pipeline of src/main.rs:156-203 at config 5's frame size against the reference's shaders on llvmpipe
+    (golden_split4k.npz, make_golden.py:split4k): the atrium at 3840 x 2160 -- primary hit records, the G-buffer made from them,
+    ray_dispatcher.frag's four targets (option "texture_filter_8bit": the noise fetch lands a few 1e-4 texels off the centres, where
+    float bilinear and llvmpipe's 8-bit weights differ in the last bits of ambientDir) and ray_trace.frag on the shadow, reflection
+    and ambient rays: nine buffers of 8.3 M pixels, every group of 16 rows hashing to llvmpipe's."""
+    import bench
+    from common import check_group_digests
+    g = load_golden("split4k")
+    w, h = (int(x) for x in g["size"])
+    model, camera, _, _, _ = bench.build_workload("atrium_1080p")
+    sc = model.scene_arrays()
+    tracer.upload_scene(sc)
+    tracer.upload_noise_texture(load_golden("dispatch2")["noise"])
+    dirs, orgs = camera.primary_rays(w, h)
+    dirs, orgs = dirs.reshape(-1, 3), orgs.reshape(-1, 3)
+    primary = tracer.trace(orgs, dirs)
+    check_group_digests(g, "primary", primary.reshape(h, w, 4))
+    pos, nm = tracer.surface_from_hits(orgs, dirs, primary, has_normals=True)
+    check_group_digests(g, "position", pos.reshape(h, w, 3))
+    check_group_digests(g, "normal_mat", nm.reshape(h, w, 4))
+    tracer.set_option("texture_filter_8bit", 1)
+    try:
+        d = tracer.dispatch_rays(pos.reshape(h, w, 3), nm.reshape(h, w, 4), g["light_pos"], g["camera_pos"], g["noise_offset_scale"])
+    finally:
+        tracer.set_option("texture_filter_8bit", 0)
+    for k in ("org", "shadow_dir", "reflect_dir", "ambient_dir"):
+        check_group_digests(g, k, d[k])
+    for k in ("shadow_dir", "reflect_dir", "ambient_dir"):
+        hits = tracer.trace(d["org"].reshape(-1, 3), d[k].reshape(-1, 3))
+        check_group_digests(g, "hits_" + k, hits.reshape(h, w, 4))
+        assert int((hits[:, 0] < 1e30).sum()) == int(g["n_hits_" + k])
+
+
 @pytest.mark.timeout(900)
 def test_full_size_soup_10m_4k(tracer, oracle_a):
     """BASELINE config 4 at full size: 10 000 000-triangle soup (seed 1, no uvs / normals), 3840x2160,
