@@ -151,6 +151,26 @@ def gather_to_root(send, gathered, rank, world, through_host=False):
         dist.gather(send, dst=0)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher's environment: start N fresh rank processes (one per GPU) with
+    torch.distributed.run on this node and return its exit status; rank 0 prints the JSON line.  Nothing in THIS process
+    touches the GPU (device_count() only counts), so the ranks start from a clean runtime.  Fewer than N GPUs is an error,
+    never a silent one-GPU run (RTAMD_BENCH_REHEARSE=1, the one-GPU rehearsal of the N > 1 code path, is exempt)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("RTAMD_BENCH_REHEARSE") != "1":
+        print(f"bench.py: --gpus {n} asked for, but this node shows {have} GPU(s); not falling back to fewer", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,6 +196,12 @@ def main():
                          "for profiler passes, where every dispatch of the kernel should hold the same number of frames")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by hand without a launcher: start the N ranks ourselves and hand their output (rank 0's line) through
+        sys.exit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     from raytracer_amd.renderer import TILE_PIXELS, HipRayTracer
@@ -183,8 +209,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     # Rehearsal on a one-GPU box (not a measurement): RTAMD_BENCH_REHEARSE=1 puts every rank on
@@ -288,17 +314,27 @@ def main():
         if as8:   # the display pass over the whole batch buffer, behind the render on the same stream
             tracer.display_rgba8_device(rgba[f].data_ptr(), n_frames * n_local_out, send[f].data_ptr())
 
-    def flush(f):
+    gather_events = []     # rank 0, timed region: (share ready, gather done, assembly done) on `stream`, one triple per batch
+    def flush(f, timed=False):
         """Gather batch buffer f (all ranks call this at the same step) and assemble its frames on the root."""
         rs = render_streams[f]
         if rs is not stream:
             stream.wait_stream(rs)
         if rehearse:
             stream.synchronize()
+        timed = timed and rank == 0
+        if timed:
+            g0, g1, a1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            g0.record(stream)       # behind the wait: this rank's own share is ready
         gather_to_root(send[f], gathered if rank == 0 else None, rank, world, rehearse)
+        if timed:
+            g1.record(stream)       # torch makes `stream` wait for the collective: every peer's share has landed
         if rank == 0:
             tracer.set_stream(stream.cuda_stream)
             tracer.assemble_tile_batch_device(gathered.data_ptr(), W, H, world, 1 if as8 else 4, B, frames_out.data_ptr())
+        if timed:
+            a1.record(stream)
+            gather_events.append((g0, g1, a1))
         consumed[f].record(stream)
 
     def run(n_steps, timed=False):
@@ -312,7 +348,7 @@ def main():
                 render_streams[f].wait_event(consumed[f])      # the buffer is free again once batch - S has been gathered
             launch(f, nf, timed)
             if world > 1:
-                flush(f)
+                flush(f, timed)
             done += nf
             batch += 1
         for rs in render_streams:
@@ -426,6 +462,16 @@ def main():
         torch.cuda.synchronize()
         serial_ms = s0.elapsed_time(s1) / n_serial
 
+    comm = None
+    if world > 1:
+        # the collective and the root's assembly reported apart from the rendering.  Spans on the root's gather
+        # stream (HIP events): "gather" starts when the root's own share is ready and ends when every peer's share has
+        # landed, so it includes waiting for the slowest peer's render, not only the transfer.
+        comm = {"backend": dist.get_backend(), "ranks": dist.get_world_size()}
+        if rank == 0 and gather_events:
+            comm["gather_ms_per_frame"] = round(sum(g0.elapsed_time(g1) for g0, g1, _ in gather_events) / args.steps, 5)
+            comm["assemble_ms_per_frame"] = round(sum(g1.elapsed_time(a1) for _, g1, a1 in gather_events) / args.steps, 5)
+            comm["bytes_per_peer_per_frame"] = n_local_out * (4 if as8 else 16)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -499,19 +545,25 @@ def main():
             roof["l1"]["path_busy_note"] = "TA_BUSY_avr / (GRBM_GUI_ACTIVE / 8) of one PMC pass: share of the kernel's cycles in which a CU's texture-address unit (the front of the L1 path) is busy"
         roof["counters_from"] = prof["source"]
         if prof.get("bound") == "tcp_access_rate" and tcp:
-            head = {"bound": "l1_access_rate", "achieved": roof["l1"]["achieved_G_s"], "peak": TCP_ACCESS_PEAK_G, "unit": "G cache-line look-ups/s",
-                    "frac": roof["l1"]["frac"],
-                    "frac_note": "TCP_TOTAL_CACHE_ACCESSES per second over one look-up per clock and CU at the 2.4 GHz maximum clock; a 16-byte lane access "
-                                 "counts two look-ups, 8- and 4-byte ones one, and the narrow ones can share a cycle, so a kernel AT the L1's limit reads a few "
-                                 "per cent above 1 (tools/micro/tcp_rate.hip sustains 2.38 look-ups per ns and CU with 16-byte accesses only)"}
+            limiter = {"resource": "l1_access_rate", "achieved": roof["l1"]["achieved_G_s"], "peak": TCP_ACCESS_PEAK_G, "unit": "G cache-line look-ups/s",
+                       "frac": roof["l1"]["frac"],
+                       "frac_note": "TCP_TOTAL_CACHE_ACCESSES per second over one look-up per clock and CU at the 2.4 GHz maximum clock; a 16-byte lane access "
+                                    "counts two look-ups, 8- and 4-byte ones one, and the narrow ones can share a cycle, so a kernel AT the L1's limit reads a few "
+                                    "per cent above 1 (tools/micro/tcp_rate.hip sustains 2.38 look-ups per ns and CU with 16-byte accesses only)"}
         else:
-            head = {"bound": "valu_issue", "achieved": round(ginst, 2), "peak": VALU_ISSUE_PEAK_GINST, "unit": "G wave64 VALU instructions/s",
-                    "frac": roof["valu"]["issue_frac"]}
-        head["traffic"] = traffic * B      # HBM bytes per launch
+            limiter = {"resource": "valu_issue", "achieved": round(ginst, 2), "peak": VALU_ISSUE_PEAK_GINST, "unit": "G wave64 VALU instructions/s",
+                       "frac": roof["valu"]["issue_frac"],
+                       "frac_note": "issued wave64 VALU instructions (SQ_INSTS_VALU, masked lanes and bookkeeping included) over 1024 SIMDs x 2.4 GHz / 2: "
+                                    "how busy the issue slots are, not how much of it is the algorithm's arithmetic - that is roofline.frac"}
+        traffic_per_launch = traffic * B      # HBM bytes per launch
     else:
-        # no counter record for this workload / variant / rank count: price the algorithmic operation count against the VALU roof
-        head = {"bound": "valu", "achieved": round(valu_tops, 3), "peak": VALU_PEAK_TOPS, "unit": "Top/s (un-fused fp32)",
-                "frac": round(valu_tops / VALU_PEAK_TOPS, 5), "traffic": None}
+        limiter, traffic_per_launch = None, None
+    # The headline fraction is SURVEY 8d's: the path's ALGORITHMIC operations (25 per AABB test, 60 per triangle test, 150 per shaded
+    # pixel, from the kernel's own per-pixel test counters) per second over the un-fused fp32 vector peak.  The scene is cache-served
+    # (algorithmic bytes exceed the HBM traffic many times over), so the byte formula is reported under roofline.hbm, not priced here.
+    head = {"bound": "valu", "achieved": round(valu_tops, 3), "peak": VALU_PEAK_TOPS, "unit": "Top/s (un-fused fp32)",
+            "frac": round(valu_tops / VALU_PEAK_TOPS, 5), "traffic": traffic_per_launch,
+            **({"issue_frac": roof["valu"]["issue_frac"], "limiter": limiter} if limiter else {})}
     out = {
         "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -521,7 +573,12 @@ def main():
                                f"{W}x{H}, 1 spp, primary + sun shadow ray + shading (fused ray_trace_and_shade semantics)",
                    "rays_per_frame": rays_per_frame, "primary_rays": n_primary_all, "shadow_rays": n_shadow_all,
                    "parallelism": f"tiles{world}" if world > 1 else "single", "kernel_variant": args.variant,
-                   "frames_per_launch": B, "streams": S, **({"gather_format": args.gather_format} if world > 1 else {}),
+                   "frames_per_launch": B, "streams": S,
+                   **({"gather_format": args.gather_format, "rccl_ranks": comm["ranks"] if comm["backend"] == "nccl" else 0,
+                       "collective_backend": comm["backend"], "gather_ms_per_frame": comm.get("gather_ms_per_frame"),
+                       "assemble_ms_per_frame": comm.get("assemble_ms_per_frame"), "gather_bytes_per_peer_per_frame": comm.get("bytes_per_peer_per_frame"),
+                       "gather_timing": "HIP events on rank 0's gather stream per batch: own share ready -> all shares landed (includes waiting "
+                                        "for the slowest peer's render) -> scan-line frames assembled; both overlap the next batch's rendering"} if world > 1 else {}),
                    **({"ms_per_frame_one_at_a_time": round(serial_ms, 5)} if serial_ms is not None else {}), "shadow_rays_stop_at_first_occluder": True,
                    **({"assembled_frame_equals_single_gpu_frame": frame_check} if frame_check is not None else {}),
                    **({"REHEARSAL_not_a_measurement": "all ranks on cuda:0, gloo gather through host memory"} if rehearse else {}),

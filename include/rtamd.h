@@ -53,7 +53,7 @@ typedef struct rtamd_context rtamd_context;
  * ray_trace_and_shade.frag:201,232-234). */
 /* Bumped whenever a struct layout or the meaning of an argument changes; a binder compares its compile-time
  * value with rtamd_abi_version() of the library it loaded.  (No counterpart in the reference.) */
-#define RTAMD_ABI_VERSION 7
+#define RTAMD_ABI_VERSION 8
 uint32_t rtamd_abi_version(void);
 
 #define RTAMD_NO_HIT 0xFFFFFFFFu
@@ -216,18 +216,21 @@ int rtamd_render_device(rtamd_context *ctx, const rtamd_frame_desc *desc, const 
 #define RTAMD_MAX_BATCH_FRAMES 16
 int rtamd_render_batch_device(rtamd_context *ctx, uint32_t n_frames, const rtamd_frame_desc *descs, const rtamd_frame_out *outs);
 
-/* rtamd_render_device for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
- * that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same outputs bit for bit, but the call
- * allocates nothing (no hipMalloc / hipFree, no event or stream creation): the launch scratch the persistent kernel
- * needs — 8 work-queue counters and the HBM columns that take the bottom of deep traversal stacks — lives in a static
- * device array of the library's code object, 64 MiB + 22 KiB, which every GPU the library runs on holds until the
- * process ends.  Limits: the uploaded scene's tree may be at most 48 levels deep (rtamd_scene_info.max_depth; 16
- * stack entries per lane in LDS + 32 in the static array), else RTAMD_ERR_INVALID_ARGUMENT; frame size as for
- * rtamd_render_device.  It always runs the persistent kernel with the context's fixed lane re-fill threshold (no
- * coherence feedback, no per-launch timing events: rtamd_last_kernel_ms / rtamd_last_launch_coherence do not see it).
- * All calls on one GPU share that GPU's array — across streams and across contexts: calls that overlap on one GPU
- * race (wrong pixels, never a fault); order them on one stream or with events.  The array keeps the last call's
- * contents; the call clears the counters itself (one 2 KB hipMemsetAsync on the context's stream). */
+/* rtamd_render_device for callers that cannot allocate: tight serving loops, harnesses that forbid hipMalloc.  No
+ * counterpart in the reference.  Same arguments, same outputs bit for bit, but the call allocates nothing (no hipMalloc /
+ * hipFree, no event or stream creation): the launch scratch the persistent kernel needs -- 8 work-queue counters and the
+ * HBM columns that take the bottom of deep traversal stacks -- lives in a static device array of the library's code
+ * object, 64 MiB + 2 KiB, which every GPU the library runs on holds until the process ends.  Limits: the uploaded
+ * scene's tree may be at most 48 levels deep (rtamd_scene_info.max_depth; 16 stack entries per lane in LDS + 32 in the
+ * static array), else RTAMD_ERR_INVALID_ARGUMENT; frame size as for rtamd_render_device.  It always runs the persistent
+ * kernel with the context's fixed lane re-fill threshold (no coherence feedback, no per-launch timing events:
+ * rtamd_last_kernel_ms / rtamd_last_launch_coherence do not see it).
+ * All calls on one GPU share that GPU's array -- across streams and across contexts.  The library orders them itself: a
+ * call's counter reset and kernel wait on the GPU (hipStreamWaitEvent on one per-device event created when the first
+ * context on that GPU is) for the previous static call's kernel, so static calls never overlap one another, whatever
+ * streams they are issued on; they may overlap every other kind of work.  The array keeps the last call's contents; the
+ * call clears the counters itself (one 2 KB hipMemsetAsync on the context's stream).  Not meant for stream capture: the
+ * call makes host-side look-ups (buffer range checks, current device) and waits on an event recorded outside a capture. */
 int rtamd_render_device_static(rtamd_context *ctx, const rtamd_frame_desc *desc, const rtamd_frame_out *out);
 
 /* ---- split-pipeline trace: ray_trace/ray_trace.frag:main (:131-143) -------- */
@@ -338,6 +341,66 @@ int rtamd_assemble_tiles_device(rtamd_context *ctx, const void *gathered, uint32
 int rtamd_assemble_tile_batch_device(rtamd_context *ctx, const void *gathered, uint32_t width, uint32_t height,
                                      uint32_t tile_world, uint32_t elems_per_pixel, uint32_t n_frames, void *frames_out);
 
+/* ---- one process, several GPUs: tile split + RCCL gather inside the library ------------------------ */
+
+/* The reference's caller is ONE single-threaded process (src/main.rs:105-243) that owns one GL context.  This is
+ * its multi-GPU counterpart behind the same kind of handle: one rtamd_context per listed GPU (the "device list" of the
+ * context), the scene replicated to each, every frame cut into interleaved 32x32 tiles (tile k -> GPU k % n, as
+ * rtamd_frame_desc.tile_rank / tile_world), each GPU rendering its tiles of a batch of frames with ONE launch, and ONE
+ * collective per batch -- ncclGather over xGMI (/opt/rocm/include/rccl/rccl.h:745; communicators from ncclCommInitAll,
+ * :236, single process) -- bringing the shares to the first listed GPU, which assembles the scan-line frames
+ * (rtamd_assemble_tile_batch_device).  No other data crosses between GPUs.  The host side is the calling thread alone.
+ * No counterpart in the reference (one GPU); the per-rank form of the same path, one process per GPU with the collective
+ * issued by the caller, is what rtamd_frame_desc.tile_* + rtamd_assemble_tile_batch_device serve. */
+typedef struct rtamd_multi rtamd_multi;
+
+/* rtamd_multi_create flags */
+#define RTAMD_MULTI_TRANSPORT_RCCL 0u   /* default: ncclGather (librccl.so.1 is loaded when the handle is created) */
+#define RTAMD_MULTI_TRANSPORT_COPY 1u   /* the root pulls the shares with hipMemcpyAsync (peer access over xGMI) instead of the
+                                         * collective.  RCCL refuses two ranks on one GPU, so this is also how the N > 1 logic
+                                         * (tile split, batch buffers, assembly) is exercised on a one-GPU box: with this flag
+                                         * the device list may name a GPU several times. */
+
+/* devices: n_devices HIP ordinals, devices[0] is the root (the assembled frames land there).  1 <= n_devices <= 64. */
+int rtamd_multi_create(const int *devices, uint32_t n_devices, uint32_t flags, rtamd_multi **out);
+void rtamd_multi_destroy(rtamd_multi *m);
+/* m == NULL: the last error of a failed rtamd_multi_create on this thread.  Never NULL. */
+const char *rtamd_multi_last_error(const rtamd_multi *m);
+uint32_t rtamd_multi_device_count(const rtamd_multi *m);
+/* The i-th GPU's context, borrowed (rtamd_get_scene_info, rtamd_last_launch_coherence ...).  Do not destroy it and do not
+ * change its stream. */
+rtamd_context *rtamd_multi_context(rtamd_multi *m, uint32_t i);
+
+/* As the single-GPU calls, applied to every GPU of the list (the scene and textures are replicated). */
+int rtamd_multi_upload_scene(rtamd_multi *m, const rtamd_scene_desc *scene);
+int rtamd_multi_upload_texture(rtamd_multi *m, uint32_t slot, const uint8_t *rgb8, uint32_t width, uint32_t height);
+int rtamd_multi_upload_materials(rtamd_multi *m, const rtamd_shading_material *materials, uint32_t count);
+int rtamd_multi_set_option(rtamd_multi *m, const char *name, int64_t value);
+
+/* What a frame is gathered as (= what crosses xGMI), and the element type of frames_out. */
+#define RTAMD_GATHER_RGBA8 0     /* the display pass's 8-bit back buffer (util/display.frag:9): one uint32_t per pixel, R in the low byte */
+#define RTAMD_GATHER_RGBA32F 1   /* fragCol itself: four floats per pixel (4x the bytes on the links) */
+
+/* n_frames (1..RTAMD_MAX_BATCH_FRAMES) frames of the fused shader, split over the GPUs of the list and assembled on the
+ * root.  descs[f] as for rtamd_render_batch_device (same width / height / has_* for all frames), except: tile_rank /
+ * tile_world are ignored (the library sets them), and dir / org, if given, are HOST arrays of width*height*3 floats that
+ * the call copies to every GPU before it returns (with dir == NULL the rays are generated on each GPU from the camera
+ * fields: nothing to copy, the usual multi-GPU form).  frames_out: n_frames * width*height pixels of the gather format,
+ * scan-line order, frame after frame -- a DEVICE pointer on the root GPU for rtamd_multi_render_batch_device, which
+ * enqueues and returns (consecutive calls alternate between two sets of share buffers, so that the gather and assembly of
+ * one batch run beside the rendering of the next; rtamd_multi_synchronize, or work ordered behind rtamd_multi_root_stream,
+ * sees the frames complete), a HOST pointer for rtamd_multi_render_batch, which waits and copies.  Every pixel equals,
+ * bit for bit, what one GPU renders alone (and converts with rtamd_display_rgba8_device for RGBA8). */
+int rtamd_multi_render_batch_device(rtamd_multi *m, uint32_t n_frames, const rtamd_frame_desc *descs, int gather_format, void *frames_out);
+int rtamd_multi_render_batch(rtamd_multi *m, uint32_t n_frames, const rtamd_frame_desc *descs, int gather_format, void *frames_out);
+/* Wait for everything the handle has enqueued on every GPU. */
+int rtamd_multi_synchronize(rtamd_multi *m);
+/* The root GPU's hipStream_t (as void*) on which gathers and assemblies run: order consumers of frames_out behind it. */
+void *rtamd_multi_root_stream(rtamd_multi *m);
+/* Milliseconds the root spent in the last batch's gather (own share ready -> all shares landed) and assembly; blocks until
+ * that batch is done.  Either may be NULL. */
+int rtamd_multi_last_gather_ms(rtamd_multi *m, float *gather_ms, float *assemble_ms);
+
 /* ---- display pass: util/display.frag:9 ------------------------------------------ */
 
 /* The reference's last pass copies the float colour target to the window's 8-bit back buffer
@@ -355,6 +418,12 @@ typedef struct rtamd_scene_info {
     uint32_t big_leaf_count;     /* leaves that need the overflow table */
     uint32_t max_depth;          /* deepest root-to-leaf path */
     uint64_t device_bytes;       /* HBM held by the scene */
+    uint32_t odd_box_count;      /* reachable nodes whose box has a non-finite bound or min > max on some axis.  The reference's
+                                  * builder never makes one (types.rs:59-99), but intersectAABB (ray_trace_and_shade.frag:53-61) is
+                                  * defined for any six floats and the C-ABI takes any caller's nodes: with one or more, every visit
+                                  * of the scene uses the general slab test instead of the direction-octant form, which equals it
+                                  * only for finite boxes with min <= max.  Results are the shader's either way. */
+    uint32_t reserved;
 } rtamd_scene_info;
 int rtamd_get_scene_info(const rtamd_context *ctx, rtamd_scene_info *info);
 

@@ -85,7 +85,7 @@ class SceneInfo(ctypes.Structure):
     _fields_ = [
         ("node_count", ctypes.c_uint32), ("triangle_count", ctypes.c_uint32), ("vertex_count", ctypes.c_uint32),
         ("inner_node_count", ctypes.c_uint32), ("big_leaf_count", ctypes.c_uint32), ("max_depth", ctypes.c_uint32),
-        ("device_bytes", ctypes.c_uint64),
+        ("device_bytes", ctypes.c_uint64), ("odd_box_count", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
     ]
 
 
@@ -141,7 +141,7 @@ def host_lib():
     return _host
 
 
-ABI_VERSION = 7   # include/rtamd.h RTAMD_ABI_VERSION
+ABI_VERSION = 8   # include/rtamd.h RTAMD_ABI_VERSION
 
 
 def device_lib():
@@ -225,6 +225,34 @@ def device_lib():
         L.rtamd_set_kernel_variant.restype = ctypes.c_int
         L.rtamd_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
         L.rtamd_set_option.restype = ctypes.c_int
+        # one process, several GPUs (rtamd_multi_*)
+        L.rtamd_multi_create.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(vp)]
+        L.rtamd_multi_create.restype = ctypes.c_int
+        L.rtamd_multi_destroy.argtypes = [vp]
+        L.rtamd_multi_destroy.restype = None
+        L.rtamd_multi_last_error.argtypes = [vp]
+        L.rtamd_multi_last_error.restype = ctypes.c_char_p
+        L.rtamd_multi_device_count.argtypes = [vp]
+        L.rtamd_multi_device_count.restype = ctypes.c_uint32
+        L.rtamd_multi_context.argtypes = [vp, ctypes.c_uint32]
+        L.rtamd_multi_context.restype = vp
+        L.rtamd_multi_upload_scene.argtypes = [vp, ctypes.POINTER(SceneDesc)]
+        L.rtamd_multi_upload_scene.restype = ctypes.c_int
+        L.rtamd_multi_upload_texture.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint32, ctypes.c_uint32]
+        L.rtamd_multi_upload_texture.restype = ctypes.c_int
+        L.rtamd_multi_upload_materials.argtypes = [vp, vp, ctypes.c_uint32]
+        L.rtamd_multi_upload_materials.restype = ctypes.c_int
+        L.rtamd_multi_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
+        L.rtamd_multi_set_option.restype = ctypes.c_int
+        for name in ("rtamd_multi_render_batch", "rtamd_multi_render_batch_device"):
+            getattr(L, name).argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(FrameDesc), ctypes.c_int, vp]
+            getattr(L, name).restype = ctypes.c_int
+        L.rtamd_multi_synchronize.argtypes = [vp]
+        L.rtamd_multi_synchronize.restype = ctypes.c_int
+        L.rtamd_multi_root_stream.argtypes = [vp]
+        L.rtamd_multi_root_stream.restype = vp
+        L.rtamd_multi_last_gather_ms.argtypes = [vp, c_float_p, c_float_p]
+        L.rtamd_multi_last_gather_ms.restype = ctypes.c_int
         L.rtamd_version.argtypes = []
         L.rtamd_version.restype = ctypes.c_char_p
         _device = L

@@ -79,6 +79,10 @@ struct SceneDev {
     const TexSlotDev *tex_slots;  // RTAMD_MAX_TEXTURE_SLOTS + 1 entries; a slot never uploaded, and the last, = the 1x1 white texel
     float root_box[6];
     uint32_t root_ref;
+    // 1: every reachable box has finite bounds with min <= max on every axis, the precondition under which slab_sel<OCT> is
+    // bit-equal to slab (rtamd_upload_scene checks; the reference builder never emits another kind, a C-ABI caller may).
+    // 0: every visit takes the general slab test.
+    uint32_t octant_ok;
 };
 
 // One frame of a batch (rtamd_render_batch_device): its rays or camera in, its pixels out.
@@ -272,7 +276,7 @@ struct StackGlobal {
     __device__ __forceinline__ void push(uint32_t, uint32_t &sp, uint32_t &sb, uint32_t v) {
         if (__builtin_expect(sp - sb >= RING, 0)) {   // ring full: its oldest entry goes to HBM
             const uint32_t e = sb / STEP;
-            if (e < (uint32_t)SPILL_STACK_ENTRIES) column(sp)[e * 64u] = lds_word(sp);   // slot (sp & mask) holds entry sb
+            if (e < (wave_words >> 6)) column(sp)[e * 64u] = lds_word(sp);   // slot (sp & mask) holds entry sb; the column has wave_words / 64 entries
             sb += STEP;
         }
         lds_word(sp, v);
@@ -283,7 +287,7 @@ struct StackGlobal {
         if (__builtin_expect(sp >= sb, 1)) return lds_word(sp);   // sp - sb carries + tid*4, so >= means "entry sp is in the ring"
         sb -= STEP;                                               // ring empty: the top entry is the last one moved out
         const uint32_t e = sb / STEP;
-        return e < (uint32_t)SPILL_STACK_ENTRIES ? column(sp)[e * 64u] : REF_NONE;
+        return e < (wave_words >> 6) ? column(sp)[e * 64u] : REF_NONE;
     }
 };
 
@@ -315,7 +319,8 @@ __device__ __forceinline__ bool slab(const Ray &r, float minx, float miny, float
 // negative; all three inverses finite and non-zero.  (lo - o) * r <= (hi - o) * r holds in
 // float for r > 0 (subtraction and multiplication by a positive number are monotonic) and
 // the reverse for r < 0, so min(t1,t2) / max(t1,t2) of `slab` are known operands, bit for
-// bit, and the six min/max per box disappear.  OCT < 0: the general test.
+// bit, and the six min/max per box disappear -- for a box with finite bounds and min <= max on every axis
+// (SceneDev::octant_ok; an inverted or NaN box decides differently under the two forms).  OCT < 0: the general test.
 template <int OCT>
 __device__ __forceinline__ bool slab_sel(const Ray &r, float minx, float miny, float minz, float maxx, float maxy, float maxz, float t, float &tmin) {
     if (OCT < 0) return slab(r, minx, miny, minz, maxx, maxy, maxz, t, tmin);
@@ -505,8 +510,12 @@ __device__ __forceinline__ V3 sample_albedo(const uint32_t *__restrict__ tex, in
 
 // Hit branch of main (:207-229) up to the shadow traversal: computes the shading
 // normal, the two candidate colours (lit / in shadow) and the shadow ray.
-template <bool MAT = false>
+// F8: how texture() filters (option "texture_filter_8bit"): 0 float bilinear, 1 the pinned executor's 8-bit filter, -1 read
+// p.tex_filter8 at run time (k_static).  The production kernel takes it as a template argument, so that the default
+// instantiation carries none of the 8-bit filter's code or registers.
+template <bool MAT = false, int F8 = -1>
 __device__ __forceinline__ void shade_primary(const SceneDev &s, const JobParams &p, const Trav &tr, V3 &col_shadow, V3 &col_lit, Ray &shadow_ray) {
+    const bool f8 = F8 < 0 ? p.tex_filter8 != 0 : F8 != 0;
     const RefTriangle tri = s.tri_idx[tr.idx];
     const float u = tr.u, v = tr.v;
     const float w = 1.0f - u - v;
@@ -551,10 +560,10 @@ __device__ __forceinline__ void shade_primary(const SceneDev &s, const JobParams
         for (int k = 0; k < 3; k++) { ka[k] = md.ka[k]; kd[k] = md.kd[k]; ks[k] = md.ks[k]; }
         ns = md.ns;
         const TexSlotDev ts = s.tex_slots[md.tex_slot];     // "no texture" is the slot of the 1x1 white texel
-        albedo = sample_albedo(ts.texels, ts.w, ts.h, tcx, -tcy, p.tex_filter8 != 0);
+        albedo = sample_albedo(ts.texels, ts.w, ts.h, tcx, -tcy, f8);
     } else {
         const uint32_t m = tri.mat_idx & 1u;
-        albedo = sample_albedo(s.tex[m], s.tex_w[m], s.tex_h[m], tcx, -tcy, p.tex_filter8 != 0);
+        albedo = sample_albedo(s.tex[m], s.tex_w[m], s.tex_h[m], tcx, -tcy, f8);
     }
     V3 sky = skybox(nx, ny, nz);
     float ndl = clamp01(dot_zyx(nx, ny, nz, sd.x, sd.y, sd.z));
@@ -670,10 +679,10 @@ __device__ __forceinline__ void store_frag_col(float *__restrict__ rgba, uint32_
 
 enum : uint32_t { PH_IDLE = 0, PH_PRIMARY = 1, PH_SHADOW = 2 };   // bits 2..5: (8 | direction octant) << 2 when the octant test applies
 enum : int { MODE_FUSED = 0, MODE_TRACE = 1 };
-__device__ __forceinline__ uint32_t ray_pos_flag(const Ray &r) {
-    // octant code for slab_sel<OCT>: all three inverse components finite and non-zero
+__device__ __forceinline__ uint32_t ray_pos_flag(const Ray &r, uint32_t octant_ok) {
+    // octant code for slab_sel<OCT>: all three inverse components finite and non-zero, in a scene whose boxes allow it
     const float inf = __builtin_inff();
-    const bool ok = fabsf(r.rx) < inf && fabsf(r.ry) < inf && fabsf(r.rz) < inf && r.rx != 0.0f && r.ry != 0.0f && r.rz != 0.0f;
+    const bool ok = octant_ok != 0u && fabsf(r.rx) < inf && fabsf(r.ry) < inf && fabsf(r.rz) < inf && r.rx != 0.0f && r.ry != 0.0f && r.rz != 0.0f;
     const uint32_t oct = (r.rx < 0.0f ? 1u : 0u) | (r.ry < 0.0f ? 2u : 0u) | (r.rz < 0.0f ? 4u : 0u);
     return ok ? ((8u | oct) << 2) : 0u;
 }
@@ -681,7 +690,7 @@ __device__ __forceinline__ uint32_t ray_pos_flag(const Ray &r) {
 // ---------------------------------------------------------------------------
 // k_persistent — production kernel
 // ---------------------------------------------------------------------------
-template <int MODE, bool COUNT, bool MAT = false>
+template <int MODE, bool COUNT, bool MAT = false, bool F8 = false>
 __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(const SceneDev s, const JobParams p) {
     __shared__ uint32_t lds_stack[LDS_STACK_ENTRIES * BLOCK];
     // fused shader: the in-shadow colour of a lane's pixel waits here ([channel][thread]) while its shadow ray is traced
@@ -803,7 +812,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                         out_index = pr.out_index | (frame << BATCH_FRAME_SHIFT);   // frame is 0 unless this is a batch
                         nbox = 0; ntri = 0;
                         trav_begin<COUNT>(s, tr, T_PRIMARY0, st.sp_init(tid), nbox);
-                        phase = PH_PRIMARY | ray_pos_flag(tr.ray);
+                        phase = PH_PRIMARY | ray_pos_flag(tr.ray, s.octant_ok);
                     }
                 } else {
                     // batch of ray lists: item -> (job, item of that job); everything here is wave-uniform
@@ -828,7 +837,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                         } else {
                             set_ray(tr.ray, o[0], o[1], o[2], d[0], d[1], d[2]);
                             trav_begin<COUNT>(s, tr, MISS, st.sp_init(tid), nbox);
-                            phase = PH_PRIMARY | ray_pos_flag(tr.ray);
+                            phase = PH_PRIMARY | ray_pos_flag(tr.ray, s.octant_ok);
                         }
                     }
                 }
@@ -939,12 +948,12 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                     if (o_id) o_id[out_i] = tr.idx;
                     Ray sray;
                     V3 col_shadow, col_lit;
-                    shade_primary<MAT>(s, p, tr, col_shadow, col_lit, sray);
+                    shade_primary<MAT, F8 ? 1 : 0>(s, p, tr, col_shadow, col_lit, sray);
                     if (o_rgba) store_frag_col(o_rgba, out_i, col_lit.x, col_lit.y, col_lit.z);
                     lds_shadow_col[tid] = col_shadow.x; lds_shadow_col[BLOCK + tid] = col_shadow.y; lds_shadow_col[2 * BLOCK + tid] = col_shadow.z;
                     tr.ray = sray;
                     trav_begin<COUNT>(s, tr, T_PRIMARY0, st.sp_init(tid), nbox);
-                    phase = PH_SHADOW | ray_pos_flag(sray);
+                    phase = PH_SHADOW | ray_pos_flag(sray, s.octant_ok);
                 } else {
                     V3 c = skybox(tr.ray.dx, tr.ray.dy, tr.ray.dz);
                     if (o_rgba) store_frag_col(o_rgba, out_i, c.x, c.y, c.z);

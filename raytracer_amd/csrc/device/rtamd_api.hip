@@ -197,6 +197,22 @@ int acquire_slot(rtamd_context *ctx, rtamd_context::Slot **out) {
     return RTAMD_OK;
 }
 
+// The fused persistent kernel's instantiation for (per-pixel counters, material table, 8-bit texture filter).
+void launch_persistent_fused(bool count, bool mat, bool f8, uint32_t grid, hipStream_t st, const SceneDev &s, const JobParams &p) {
+#define RTAMD_FUSED(C, M, F) hipLaunchKernelGGL((k_persistent<MODE_FUSED, C, M, F>), dim3(grid), dim3(BLOCK), 0, st, s, p)
+    switch ((count ? 4 : 0) | (mat ? 2 : 0) | (f8 ? 1 : 0)) {
+        case 0: RTAMD_FUSED(false, false, false); break;
+        case 1: RTAMD_FUSED(false, false, true); break;
+        case 2: RTAMD_FUSED(false, true, false); break;
+        case 3: RTAMD_FUSED(false, true, true); break;
+        case 4: RTAMD_FUSED(true, false, false); break;
+        case 5: RTAMD_FUSED(true, false, true); break;
+        case 6: RTAMD_FUSED(true, true, false); break;
+        default: RTAMD_FUSED(true, true, true); break;
+    }
+#undef RTAMD_FUSED
+}
+
 // Launch the traversal kernel selected by (mode, count, variant) for `p`.
 int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     if (p.n_items == 0) return RTAMD_OK;
@@ -262,12 +278,8 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
         uint32_t need = (p.n_items + (BLOCK / 64) - 1) / (BLOCK / 64);
         if (grid > need) grid = need;
         if (grid < 1) grid = 1;
-        if (mode == MODE_FUSED && mat) {
-            if (count) hipLaunchKernelGGL((k_persistent<MODE_FUSED, true, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
-            else hipLaunchKernelGGL((k_persistent<MODE_FUSED, false, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
-        } else if (mode == MODE_FUSED) {
-            if (count) hipLaunchKernelGGL((k_persistent<MODE_FUSED, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
-            else hipLaunchKernelGGL((k_persistent<MODE_FUSED, false>), dim3(grid), dim3(BLOCK), 0, st, s, p);
+        if (mode == MODE_FUSED) {
+            launch_persistent_fused(count, mat, ctx->tex_filter8, grid, st, s, p);
         } else {
             if (count) hipLaunchKernelGGL((k_persistent<MODE_TRACE, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
             else hipLaunchKernelGGL((k_persistent<MODE_TRACE, false>), dim3(grid), dim3(BLOCK), 0, st, s, p);
@@ -299,8 +311,12 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
 // is part of the code object, so every GPU the library runs on holds its own copy until the process ends:
 //   [ 8 queue counters, 256 B apart (2 KB) | stack columns [8192 waves][32 entries][64 lanes] u32 (64 MiB) | guard ]
 // 8192 waves = the full persistent grid (256 CUs x 8 workgroups x 4 waves); 32 entries beyond the 16 of the
-// LDS ring = trees up to depth 48 (deeper scenes are refused by the entry point; the guard keeps even the
-// kernel's own compile-time entry bound, SPILL_STACK_ENTRIES, inside the array for the last wave).
+// LDS ring = trees up to depth 48 (deeper scenes are refused by the entry point, and the kernel bounds every
+// column access by the per-launch entry count it is given, spill_wave_words / 64, so a wave cannot reach its
+// neighbour's column whatever the tree).
+// All static calls on a GPU share the array, across streams and contexts: the entry point orders them with one
+// event per device (g_static_done: each call's launches wait for the previous call's kernel), so overlapping
+// callers are serialised on the GPU instead of popping each other's stack entries.
 // `scratch` is a host-side stand-in here, not a device address: host code uses static_scratch_ptr().
 constexpr uint32_t STATIC_WAVES = 8192;
 constexpr uint32_t STATIC_SPILL_ENTRIES = 32;
@@ -308,12 +324,12 @@ constexpr uint32_t STATIC_MAX_DEPTH = (uint32_t)LDS_STACK_ENTRIES + STATIC_SPILL
 constexpr uint32_t STATIC_QUEUES = 8, STATIC_QUEUE_STRIDE = 64;
 constexpr size_t STATIC_QUEUE_WORDS = (size_t)STATIC_QUEUES * STATIC_QUEUE_STRIDE;
 constexpr size_t STATIC_SPILL_WORDS = (size_t)STATIC_WAVES * STATIC_SPILL_ENTRIES * 64;
-constexpr size_t STATIC_GUARD_WORDS = (size_t)(SPILL_STACK_ENTRIES > (int)STATIC_SPILL_ENTRIES ? SPILL_STACK_ENTRIES - (int)STATIC_SPILL_ENTRIES : 0) * 64;
-static __device__ __align__(256) uint32_t scratch[STATIC_QUEUE_WORDS + STATIC_SPILL_WORDS + STATIC_GUARD_WORDS];
+static __device__ __align__(256) uint32_t scratch[STATIC_QUEUE_WORDS + STATIC_SPILL_WORDS];
 
 constexpr int MAX_DEVICES = 64;
 std::mutex g_scratch_mutex;
 uint32_t *g_scratch_ptr[MAX_DEVICES] = {};
+hipEvent_t g_static_done[MAX_DEVICES] = {};    // recorded behind the kernel of the last static call on the device
 
 // The device address of `scratch` on the context's GPU (which must be current): looked up once per device.
 int static_scratch_ptr(rtamd_context *ctx, uint32_t **out) {
@@ -323,6 +339,10 @@ int static_scratch_ptr(rtamd_context *ctx, uint32_t **out) {
         uint32_t *ptr = nullptr;
         HIP_TRY(ctx, hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
         if (!ptr) return fail(ctx, RTAMD_ERR_DEVICE, "hipGetSymbolAddress returned NULL for the static launch scratch");
+        hipEvent_t ev = nullptr;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(ev, nullptr));      // a recorded event from the start: the first call's wait is a no-op
+        g_static_done[ctx->device] = ev;
         g_scratch_ptr[ctx->device] = ptr;
     }
     *out = g_scratch_ptr[ctx->device];
@@ -561,6 +581,10 @@ int rtamd_upload_scene(rtamd_context *ctx, const rtamd_scene_desc *sc) {
         std::vector<std::pair<uint32_t, uint32_t>> todo;
         todo.emplace_back(0u, 0u);
         uint32_t max_depth = 0;
+        // Boxes the octant slab test may not see (intersectAABB, ray_trace_and_shade.frag:53-61, is defined for any six floats;
+        // slab_sel<OCT> equals it only for finite bounds with min <= max): counted here, over the reachable nodes; one such
+        // box routes every visit of the scene through the general test (SceneDev::octant_ok).
+        uint32_t odd_boxes = 0;
         while (!todo.empty()) {
             auto [ni, depth] = todo.back();
             todo.pop_back();
@@ -568,6 +592,11 @@ int rtamd_upload_scene(rtamd_context *ctx, const rtamd_scene_desc *sc) {
             if (state[ni]) return fail(ctx, RTAMD_ERR_MALFORMED_SCENE, "node %u is reachable twice (not a tree)", ni);
             if (depth > max_depth) max_depth = depth;
             const RefNode &nd = nodes[ni];
+            {
+                bool odd = false;
+                for (int k = 0; k < 3; k++) odd = odd || !std::isfinite(nd.bounds[k]) || !std::isfinite(nd.bounds[3 + k]) || !(nd.bounds[k] <= nd.bounds[3 + k]);
+                if (odd) odd_boxes++;
+            }
             if (nd.is_leaf) {
                 state[ni] = 2;
                 if ((uint64_t)nd.a + nd.b > n_tris) return fail(ctx, RTAMD_ERR_MALFORMED_SCENE, "leaf %u covers triangles [%u, %u+%u) beyond %u", ni, nd.a, nd.a, nd.b, n_tris);
@@ -659,9 +688,11 @@ int rtamd_upload_scene(rtamd_context *ctx, const rtamd_scene_desc *sc) {
         }
         for (int k = 0; k < 6; k++) s.root_box[k] = nodes[0].bounds[k];
         s.root_ref = root_ref;
+        s.octant_ok = odd_boxes == 0 ? 1u : 0u;
 
         ctx->info.node_count = n_nodes; ctx->info.triangle_count = n_tris; ctx->info.vertex_count = n_verts;
         ctx->info.inner_node_count = n_inner; ctx->info.big_leaf_count = (uint32_t)big.size(); ctx->info.max_depth = max_depth;
+        ctx->info.odd_box_count = odd_boxes; ctx->info.reserved = 0;
         ctx->info.device_bytes = ctx->nodes.bytes + ctx->tris.bytes + ctx->big.bytes + ctx->tri_idx.bytes + ctx->normals.bytes + ctx->texcoords.bytes;
         ctx->has_scene = true;
     } catch (const std::bad_alloc &) {
@@ -951,6 +982,11 @@ int rtamd_render_device_static(rtamd_context *ctx, const rtamd_frame_desc *desc,
     p.stamps = nullptr;
 #endif
     hipStream_t st = ctx->stream;
+    // One static call at a time per GPU: this call's counter reset and kernel wait (on the GPU) for the kernel of the previous
+    // static call on this device, whatever stream or context issued it, and the host-side sequence wait -> reset -> launch ->
+    // record is atomic under the mutex, so two threads cannot interleave theirs.  Neither call allocates.
+    std::lock_guard<std::mutex> static_lock(g_scratch_mutex);
+    HIP_TRY(ctx, hipStreamWaitEvent(st, g_static_done[ctx->device], 0));
     // the array keeps the previous call's contents: the counters must start at zero (the stack columns need no clearing:
     // an entry is written before it is read)
     HIP_TRY(ctx, hipMemsetAsync(ptr, 0, STATIC_QUEUE_WORDS * sizeof(uint32_t), st));
@@ -963,14 +999,9 @@ int rtamd_render_device_static(rtamd_context *ctx, const rtamd_frame_desc *desc,
     if (grid > need) grid = need;
     if (grid > cap) grid = cap;     // the stack columns exist for STATIC_WAVES waves
     if (grid < 1) grid = 1;
-    if (mat) {
-        if (count) hipLaunchKernelGGL((k_persistent<MODE_FUSED, true, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
-        else hipLaunchKernelGGL((k_persistent<MODE_FUSED, false, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
-    } else {
-        if (count) hipLaunchKernelGGL((k_persistent<MODE_FUSED, true>), dim3(grid), dim3(BLOCK), 0, st, s, p);
-        else hipLaunchKernelGGL((k_persistent<MODE_FUSED, false>), dim3(grid), dim3(BLOCK), 0, st, s, p);
-    }
+    launch_persistent_fused(count, mat, ctx->tex_filter8, grid, st, s, p);
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(g_static_done[ctx->device], st));
     if (out->rgba8) {
         const uint32_t n_tiles = n_tiles_of(desc->width, desc->height, nullptr);
         const uint64_t n_out = desc->tile_world == 1 ? (uint64_t)desc->width * desc->height

@@ -314,6 +314,105 @@ class HipRayTracer:
                                                                elems_per_pixel, n_frames, ctypes.c_void_p(frames_ptr)))
 
 
+GATHER_RGBA8, GATHER_RGBA32F = 0, 1
+TRANSPORT_RCCL, TRANSPORT_COPY = 0, 1
+
+
+class MultiGpuRayTracer:
+    """rtamd_multi_* (include/rtamd.h): ONE process driving several GPUs — a context per GPU, the scene replicated, frames cut
+    into interleaved 32x32 tiles, one ncclGather per batch inside the library, the scan-line frames assembled on devices[0]."""
+
+    def __init__(self, devices, transport=TRANSPORT_RCCL):
+        self._lib = _ffi.device_lib()
+        devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        h = ctypes.c_void_p()
+        rc = self._lib.rtamd_multi_create(devs, len(devices), int(transport), ctypes.byref(h))
+        if rc != 0:
+            raise RtamdError(rc, self._lib.rtamd_multi_last_error(None).decode())
+        self._h = h
+        self.n = len(devices)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rtamd_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RtamdError(rc, self._lib.rtamd_multi_last_error(self._h).decode())
+
+    def upload_scene(self, scene):
+        nodes = np.ascontiguousarray(scene["nodes"])
+        tris = np.ascontiguousarray(scene["triangles"])
+        pos = np.ascontiguousarray(scene["positions"], dtype=np.float32)
+        tc, nr = scene.get("tex_coords"), scene.get("normals")
+        tc = None if tc is None else np.ascontiguousarray(tc, dtype=np.float32)
+        nr = None if nr is None else np.ascontiguousarray(nr, dtype=np.float32)
+        d = _ffi.SceneDesc(nodes.ctypes.data, len(nodes), tris.ctypes.data, len(tris), pos.ctypes.data, pos.size // 3,
+                           None if tc is None else tc.ctypes.data, None if nr is None else nr.ctypes.data)
+        self._check(self._lib.rtamd_multi_upload_scene(self._h, ctypes.byref(d)))
+
+    def upload_texture(self, slot, rgb8):
+        t = np.ascontiguousarray(rgb8, dtype=np.uint8)
+        self._check(self._lib.rtamd_multi_upload_texture(self._h, int(slot), ctypes.c_void_p(t.ctypes.data), t.shape[1], t.shape[0]))
+
+    def set_option(self, name, value):
+        self._check(self._lib.rtamd_multi_set_option(self._h, name.encode(), int(value)))
+
+    def _descs(self, width, height, frames, has_tex_coords, has_normals):
+        descs = (_ffi.FrameDesc * len(frames))()
+        keep = []
+        for k, fr in enumerate(frames):
+            d = descs[k]
+            d.width, d.height = int(width), int(height)
+            if "dir" in fr:     # host rays
+                a = np.ascontiguousarray(fr["dir"], dtype=np.float32).reshape(-1, 3)
+                o = np.ascontiguousarray(fr["org"], dtype=np.float32).reshape(-1, 3)
+                if len(a) != width * height or len(o) != width * height:
+                    raise ValueError("dir/org must hold width*height rays")
+                keep += [a, o]
+                d.dir, d.org = a.ctypes.data, o.ctypes.data
+            else:
+                inv, pos = fr["camera"]
+                inv = np.asarray(inv, dtype=np.float32).reshape(16)
+                for i in range(16):
+                    d.inv_proj_view[i] = float(inv[i])
+                for i in range(3):
+                    d.cam_pos[i] = float(np.float32(pos[i]))
+            d.near_plane, d.far_plane = NEAR, FAR
+            d.has_tex_coords, d.has_normals = int(bool(has_tex_coords)), int(bool(has_normals))
+            d.tile_rank, d.tile_world = 0, 1
+        return descs, keep
+
+    def render_batch(self, width, height, frames, gather_format=GATHER_RGBA8, has_tex_coords=False, has_normals=False):
+        """frames: dicts with "camera": (inv_proj_view, position) or "dir" / "org" host arrays.  Returns (n_frames, h*w) uint32
+        for RGBA8, (n_frames, h*w, 4) float32 for RGBA32F (host arrays; synchronous)."""
+        descs, keep = self._descs(width, height, frames, has_tex_coords, has_normals)
+        n = len(frames)
+        out = np.zeros((n, width * height), np.uint32) if gather_format == GATHER_RGBA8 else np.zeros((n, width * height, 4), np.float32)
+        self._check(self._lib.rtamd_multi_render_batch(self._h, n, descs, int(gather_format), ctypes.c_void_p(out.ctypes.data)))
+        return out
+
+    def render_batch_device(self, width, height, frames, frames_out_ptr, gather_format=GATHER_RGBA8, has_tex_coords=False, has_normals=False):
+        """Asynchronous: frames_out_ptr is a device address on devices[0]; see rtamd_multi_render_batch_device."""
+        descs, keep = self._descs(width, height, frames, has_tex_coords, has_normals)
+        self._check(self._lib.rtamd_multi_render_batch_device(self._h, len(frames), descs, int(gather_format), ctypes.c_void_p(frames_out_ptr)))
+
+    def synchronize(self):
+        self._check(self._lib.rtamd_multi_synchronize(self._h))
+
+    def root_stream(self):
+        return self._lib.rtamd_multi_root_stream(self._h)
+
+    def last_gather_ms(self):
+        g, a = ctypes.c_float(), ctypes.c_float()
+        self._check(self._lib.rtamd_multi_last_gather_ms(self._h, ctypes.byref(g), ctypes.byref(a)))
+        return g.value, a.value
+
+
 def assemble_tiles_host(blocks, width, height, tile_world, elems):
     """Pure-numpy statement of the tile layout (used by CPU tests of the sharding
     logic): blocks[r] is rank r's compact tile-major array (n_local*1024, elems)."""

@@ -6,7 +6,12 @@
  * (:204-230) and the split trace pass (ray_trace.frag), then tear down — and exercises the error contract on the way
  * (empty scene, render before upload, malformed tree).
  *
- *   drop_in <scene.bin> <out.bin>     scene.bin / out.bin: see tests/test_c_caller.py, which writes one and reads the other
+ *   drop_in <scene.bin> <out.bin> [--gpus n] [--copy]
+ *       scene.bin / out.bin: see tests/test_c_caller.py, which writes one and reads the other.
+ *       --gpus n: after the single-GPU pass, the same frame through the one-process multi-GPU entry points
+ *       (rtamd_multi_*: tile split over n GPUs, ncclGather inside the library, assembly on the first) must come out bit for
+ *       bit as the single context rendered it, in both gather formats.  --copy: n contexts on GPU 0 with the copy transport
+ *       (RCCL takes one rank per GPU), which is how the n > 1 logic runs on a one-GPU box.
  *
  * Exit status: 0 ok; 3 no usable GPU (RTAMD_ERR_DEVICE from rtamd_context_create: the library has no CPU fallback);
  * anything else a failure, with the reason on stderr.  Built by __graft_entry__.build():
@@ -46,6 +51,52 @@ static int expect(rtamd_context *ctx, int rc, int want, const char *what) {
     return 0;
 }
 
+/* The frame of `fd` (host rays) twice in one batch through rtamd_multi_*: every pixel of both frames, in both gather
+ * formats, must equal what the single context produced (want32 / want8). */
+static int multi_gpu_leg(uint32_t n, uint32_t copy, const rtamd_scene_desc *sd, uint8_t *tex[2], const uint32_t tex_w[2], const uint32_t tex_h[2],
+                         const rtamd_frame_desc *fd, const float *want32, const uint32_t *want8) {
+    int devices[64];
+    for (uint32_t i = 0; i < n; i++) devices[i] = copy ? 0 : (int)i;
+    rtamd_multi *m = NULL;
+    int rc = rtamd_multi_create(devices, n, copy ? RTAMD_MULTI_TRANSPORT_COPY : RTAMD_MULTI_TRANSPORT_RCCL, &m);
+    if (rc != RTAMD_OK) {
+        fprintf(stderr, "drop_in: rtamd_multi_create(%u GPUs): %d (%s)\n", n, rc, rtamd_multi_last_error(NULL));
+        return 30;
+    }
+    int bad = 0;
+    const size_t n_px = (size_t)fd->width * fd->height;
+    float *got32 = malloc(2 * n_px * 16);
+    uint32_t *got8 = malloc(2 * n_px * 4);
+    if (!got32 || !got8) return 17;
+    if (rtamd_multi_device_count(m) != n || !rtamd_multi_context(m, n - 1) || rtamd_multi_context(m, n)) bad++;
+    rc = rtamd_multi_upload_scene(m, sd);
+    for (uint32_t k = 0; k < 2 && rc == RTAMD_OK; k++)
+        if (tex[k]) rc = rtamd_multi_upload_texture(m, k, tex[k], tex_w[k], tex_h[k]);
+    rtamd_frame_desc two[2];
+    two[0] = *fd; two[1] = *fd;
+    for (int pass = 0; pass < 3 && rc == RTAMD_OK; pass++) {      /* three calls: both sets of share buffers, and one of them again */
+        if (rc == RTAMD_OK) rc = rtamd_multi_render_batch(m, 2, two, RTAMD_GATHER_RGBA8, got8);
+        if (rc == RTAMD_OK) rc = rtamd_multi_render_batch(m, 2, two, RTAMD_GATHER_RGBA32F, got32);
+        if (rc == RTAMD_OK)
+            for (int f = 0; f < 2; f++) {
+                if (memcmp(got8 + f * n_px, want8, n_px * 4)) { fprintf(stderr, "drop_in: multi-GPU RGBA8 frame %d differs (pass %d)\n", f, pass); bad++; }
+                if (memcmp(got32 + 4 * f * n_px, want32, n_px * 16)) { fprintf(stderr, "drop_in: multi-GPU RGBA32F frame %d differs (pass %d)\n", f, pass); bad++; }
+            }
+    }
+    float g_ms = -1.0f, a_ms = -1.0f;
+    if (rc == RTAMD_OK) rc = rtamd_multi_last_gather_ms(m, &g_ms, &a_ms);
+    if (rc == RTAMD_OK) rc = rtamd_multi_synchronize(m);
+    if (rc != RTAMD_OK) { fprintf(stderr, "drop_in: multi-GPU leg: %d (%s)\n", rc, rtamd_multi_last_error(m)); bad++; }
+    /* the error contract: 17 frames, an unknown format */
+    if (rtamd_multi_render_batch(m, 17, two, RTAMD_GATHER_RGBA8, got8) != RTAMD_ERR_INVALID_ARGUMENT || rtamd_multi_last_error(m)[0] == '\0') bad++;
+    if (rtamd_multi_render_batch(m, 2, two, 7, got8) != RTAMD_ERR_INVALID_ARGUMENT) bad++;
+    rtamd_multi_destroy(m);
+    free(got32); free(got8);
+    if (bad) return 21;
+    printf("multi ok: %u GPU(s), %s transport, gather %.3f ms, assembly %.3f ms\n", n, copy ? "copy" : "RCCL", g_ms, a_ms);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (rtamd_abi_version() != RTAMD_ABI_VERSION) {
         fprintf(stderr, "drop_in: header ABI %d, library ABI %u\n", RTAMD_ABI_VERSION, rtamd_abi_version());
@@ -61,8 +112,14 @@ int main(int argc, char **argv) {
         fprintf(stderr, "drop_in: rtamd_context_create: %d (%s)\n", rc, rtamd_last_error(NULL));
         return 13;
     }
-    if (argc != 3) {
-        fprintf(stderr, "usage: drop_in scene.bin out.bin\n");
+    uint32_t multi_gpus = 0, multi_copy = 0;
+    for (int a = 3; a < argc; a++) {
+        if (!strcmp(argv[a], "--gpus") && a + 1 < argc) multi_gpus = (uint32_t)strtoul(argv[++a], NULL, 10);
+        else if (!strcmp(argv[a], "--copy")) multi_copy = 1;
+        else argc = 0;
+    }
+    if (argc < 3 || multi_gpus > 64) {
+        fprintf(stderr, "usage: drop_in scene.bin out.bin [--gpus n] [--copy]\n");
         rtamd_context_destroy(ctx);
         return 14;
     }
@@ -128,6 +185,10 @@ int main(int argc, char **argv) {
     bad += expect(ctx, rtamd_synchronize(ctx), RTAMD_OK, "rtamd_synchronize");
     rtamd_context_destroy(ctx);
     if (bad) return 20;
+    if (multi_gpus) {
+        const int mrc = multi_gpu_leg(multi_gpus, multi_copy, &sd, tex, h.tex_w, h.tex_h, &fd, rgba, rgba8);
+        if (mrc) return mrc;
+    }
 
     f = fopen(argv[2], "wb");
     if (!f) { perror(argv[2]); return 18; }

@@ -80,3 +80,20 @@ def test_c_caller_renders_the_reference_pixels(tmp_path, name):
     q = np.floor(c * 255 + 0.5).astype(np.uint32)
     got = np.stack([(rgba8 >> s) & 255 for s in (0, 8, 16, 24)], 1)
     assert np.abs(got.astype(np.int64) - q.astype(np.int64)).max() <= 1 and (got == q).mean() > 0.999
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,transport", [(["--gpus", "1"], "RCCL"), (["--gpus", "3", "--copy"], "copy"), (["--gpus", "1", "--copy"], "copy")])
+def test_c_caller_multi_gpu_entry_points_reproduce_the_single_gpu_frame(tmp_path, args, transport):
+    """The one-process multi-GPU entry points (rtamd_multi_*) from the C99 program: `--gpus 1` goes through RCCL itself
+    (ncclCommInitAll + ncclGather with a world of one: all that a one-GPU box can show of the real collective);
+    `--gpus 3 --copy` runs the N > 1 logic — interleaved tiles per context, two alternating sets of share buffers, assembly
+    on the root — with three contexts on GPU 0 and the copy transport.  The program itself compares every pixel of both
+    gather formats with the single context's frame and exits non-zero on a difference."""
+    exe = BIN if os.path.exists(BIN) else _compile(str(tmp_path / "drop_in"))
+    g = load_golden("f16")
+    scene, out = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")
+    _write_scene(scene, g)
+    p = subprocess.run([exe, scene, out] + args, capture_output=True, text=True, timeout=200)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
+    assert f"multi ok: {args[1]} GPU(s), {transport} transport" in p.stdout, p.stdout

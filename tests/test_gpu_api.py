@@ -640,6 +640,7 @@ def _batch_vs_single(tracer, w, h, frames_in, has_tc, has_n, tile_rank=0, tile_w
     for fin in frames_in:      # the library cannot know a device buffer's size: a short ray array would be read out of bounds
         assert "camera" in fin or (fin["dir"].numel() == 3 * w * h and fin["org"].numel() == 3 * w * h)
     single, batch = [outputs() for _ in frames_in], [outputs() for _ in frames_in]
+    torch.cuda.synchronize()    # the fills ran on torch's stream, the library launches on the context's own non-blocking stream
     for fin, o in zip(frames_in, single):
         tracer.render_device(w, h, has_tex_coords=has_tc, has_normals=has_n, tile_rank=tile_rank, tile_world=tile_world, **args(fin, o))
     tracer.render_batch_device(w, h, [args(fin, o) for fin, o in zip(frames_in, batch)], has_tex_coords=has_tc, has_normals=has_n,
@@ -808,6 +809,7 @@ def test_trace_batch_equals_list_by_list(tracer, dyn_thresh):
             tracer.set_kernel_variant(variant)
             for _, _, hb, _ in bufs:
                 hb.fill_(-3.0)
+            torch.cuda.synchronize()    # uploads and fills ran on torch's stream, the library launches on the context's own
             tracer.trace_batch_device(jobs)
             for n, (t_org, t_dir, _, hits_s) in zip(lengths, bufs):
                 if n:

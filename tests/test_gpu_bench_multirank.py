@@ -22,12 +22,16 @@ def _free_port():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("fmt,steps,gather_batch", [("rgba8", 6, 4), ("f32", 6, 4), ("rgba8", 3, 1)])
-def test_two_rank_rehearsal_assembles_the_single_gpu_frame(fmt, steps, gather_batch):
+@pytest.mark.parametrize("fmt,steps,gather_batch,launcher", [("rgba8", 6, 4, "torchrun"), ("f32", 6, 4, "self"), ("rgba8", 3, 1, "torchrun")])
+def test_two_rank_rehearsal_assembles_the_single_gpu_frame(fmt, steps, gather_batch, launcher):
+    """launcher "torchrun": the driver's command line.  "self": plain `python bench.py --gpus 2`, which starts its own ranks."""
     env = dict(os.environ, RTAMD_BENCH_REHEARSE="1", OMP_NUM_THREADS="4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--workload", "atrium_small",
-           "--steps", str(steps), "--warmup", "3", "--no-cpu-baseline", "--gather-format", fmt, "--gather-batch", str(gather_batch)]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    head = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+             "--master-port", str(_free_port())] if launcher == "torchrun" else [sys.executable])
+    cmd = head + [os.path.join(REPO, "bench.py"), "--gpus", "2", "--workload", "atrium_small",
+                  "--steps", str(steps), "--warmup", "3", "--no-cpu-baseline", "--gather-format", fmt, "--gather-batch", str(gather_batch)]
     p = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=500)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -38,6 +42,9 @@ def test_two_rank_rehearsal_assembles_the_single_gpu_frame(fmt, steps, gather_ba
     assert steps % gather_batch != 0 or gather_batch == 1    # 6 steps in batches of 4: the last batch is partial
     assert cfg["assembled_frame_equals_single_gpu_frame"] is True
     assert "REHEARSAL_not_a_measurement" in cfg
+    # the collective and the root's assembly are reported apart from the rendering; gloo here, so no RCCL ranks
+    assert cfg["collective_backend"] == "gloo" and cfg["rccl_ranks"] == 0
+    assert cfg["gather_ms_per_frame"] > 0 and cfg["assemble_ms_per_frame"] > 0
     assert out["value"] > 0 and out["steps"] == steps and out["scaling"] == "strong"
     # rays are counted over both ranks' shares: the whole frame's primaries
     assert cfg["primary_rays"] == 480 * 270

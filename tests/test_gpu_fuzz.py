@@ -190,3 +190,52 @@ def test_random_gbuffers_dispatch_match_oracle(tracer, oracle_a):
                 fa, fr = np.isfinite(a[k]), np.isfinite(r[k])
                 assert np.array_equal(fa, fr), (rep, k, filter8)
                 assert np.array_equal(bits(a[k])[fa], bits(r[k])[fa]), (rep, k, w, h, filter8)
+
+
+def test_odd_boxes_match_oracle(tracer, oracle_a):
+    """intersectAABB (ray_trace_and_shade.frag:53-61) is defined for any six floats, and the C-ABI takes any caller's nodes:
+    boxes with min > max on an axis, NaN bounds and infinite bounds, which the reference's builder never emits.  The
+    direction-octant slab test equals the general one only for finite boxes with min <= max, so such a scene is routed
+    through the general test (rtamd_scene_info.odd_box_count > 0): trace and fused hit buffers equal oracle A bit for bit,
+    both kernel variants.  Rays are general-position ones, i.e. the ones that WOULD take the octant path."""
+    import os
+    seed, reps = int(os.environ.get("RTAMD_FUZZ_SEED", "0")), int(os.environ.get("RTAMD_FUZZ_REPS", "12"))
+    rng = np.random.default_rng(18 + 1000 * seed)
+    try:
+        for rep in range(reps):
+            sc, tri_pos = _scene(rng, "soup")
+            tracer.upload_scene(sc)
+            assert tracer.scene_info().odd_box_count == 0
+            nodes = sc["nodes"].copy()
+            cand = np.array([i for i in range(len(nodes)) if i != 1])          # node 1 is the builder's unreachable dummy
+            picks = rng.choice(cand, size=max(1, len(cand) // 6), replace=False)
+            for i in picks:
+                b = nodes["bounds"][i]
+                kind, ax = rng.integers(0, 4), rng.integers(0, 3)
+                if kind == 0:
+                    b[ax], b[3 + ax] = b[3 + ax], b[ax]                        # inverted on one axis
+                    if b[ax] == b[3 + ax]:
+                        b[ax] += np.float32(1.0)
+                elif kind == 1:
+                    b[rng.integers(0, 6)] = np.float32(np.nan)
+                elif kind == 2:
+                    b[ax], b[3 + ax] = np.float32(-np.inf), np.float32(np.inf)  # an infinite slab
+                else:
+                    b[3 + ax] = np.float32(-np.inf) if rng.random() < 0.5 else np.float32(np.inf)
+                nodes["bounds"][i] = b
+            sc2 = dict(sc, nodes=nodes)
+            n = int(rng.integers(64, 3000))
+            org, d = _rays(rng, tri_pos, n)
+            d[~d.any(axis=1)] = np.float32([0.3, -0.5, 0.8])
+            tracer.upload_scene(sc2)
+            assert tracer.scene_info().odd_box_count == len(picks)
+            want = oracle_a.trace(sc2, org, d)["hits"]
+            a = oracle_a.render(sc2, d, org, 0, 0)
+            for variant in (0, 1):
+                tracer.set_kernel_variant(variant)
+                got = tracer.trace(org, d)
+                assert np.array_equal(bits(got), bits(want)), (rep, variant, int((bits(got) != bits(want)).any(axis=1).sum()))
+                r = tracer.render(n, 1, dir=d, org=org, has_tex_coords=0, has_normals=0)
+                assert np.array_equal(a["hit_id"], r["hit_id"]) and np.array_equal(bits(a["hit_t"]), bits(r["hit_t"])), (rep, variant)
+    finally:
+        tracer.set_kernel_variant(0)
