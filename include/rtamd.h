@@ -323,6 +323,62 @@ typedef struct rtamd_dispatch_out {
 int rtamd_dispatch_rays(rtamd_context *ctx, const rtamd_dispatch_desc *desc, const rtamd_dispatch_out *out);
 int rtamd_dispatch_rays_device(rtamd_context *ctx, const rtamd_dispatch_desc *desc, const rtamd_dispatch_out *out);
 
+/* ---- multi-sample, multi-bounce chain: src/main.rs:143-203 repeated ---------------------------------- */
+
+/* One sample of one frame, as the reference's frame loop wires it (src/main.rs:143-203) and repeated per bounce:
+ *     primaries      ray_create.frag:12 at sample position s inside the pixel      rtamd_generate_rays_tiles_device
+ *     closest hit    ray_trace.frag:131-143                                         rtamd_trace[_batch]_device
+ *     for depth 1..max_depth:
+ *         G-buffer   the rasteriser pass's outputs, from the hit records            rtamd_surface_from_hits_device
+ *         dispatcher ray_dispatcher.frag:26-41                                       rtamd_dispatch_rays_device
+ *         shadow ray ray_trace.frag on (org, shadow_dir)                             -> shadow_hits
+ *         continuation (not after the last depth): ray_trace.frag on (org, reflect_dir) for even s, (org, ambient_dir)
+ *                    for odd s                                                       -> hits (replacing the previous bounce's)
+ * rtamd_multibounce_sample_batch_device runs this for up to 8 samples in lock step: every stage's traversals of all
+ * samples go out as ONE rtamd_trace_batch_device launch (n primaries; then n shadow + n continuation lists per bounce), the
+ * per-pixel stages as one launch per sample, all on the context's stream; it returns without waiting.  It is launches and
+ * buffer rotation only: every buffer holds, bit for bit, what the single calls named above write.  Sample s sits at
+ * (frac(0.5 + s*g), frac(0.5 + s*g*g)) inside the pixel (R2 sequence, g = 0.7548776662466927; s = 0 is the pixel centre the
+ * reference rasterises); the dispatcher's noise offset for (s, depth) is ((7s + 3 depth) mod noise_size,
+ * (11s + 5 depth) mod noise_size) / noise_size with scale (width, height) / noise_size (src/main.rs:161-166 uses a random
+ * offset per frame).  No colour comes out: the reference's consumer of these records (shader.frag:120-124) is a stub. */
+typedef struct rtamd_multibounce_desc {
+    uint32_t width, height;
+    float inv_proj_view[16];
+    float near_plane, far_plane;
+    float cam_pos[3];
+    float light_pos[3];
+    uint32_t has_normals;
+    uint32_t max_depth;              /* bounces, 1..16 */
+    uint32_t noise_size;             /* texel grid the noise offsets step over (the reference's blue_noise.png: 512) */
+    uint32_t tile_rank, tile_world;  /* tile shard of the frame (tile_world 0 or 1: the whole frame); buffers then hold local
+                                      * tiles * 1024 entries in the compact tile-major layout */
+} rtamd_multibounce_desc;
+
+/* The device buffers of one sample in flight, n = rtamd_multibounce_entries(desc) entries each (floats per entry in
+ * brackets); 16-byte aligned.  cam_org is filled once by rtamd_multibounce_prepare_lane_device; everything else is
+ * written by every sample.  The two sets of dispatcher targets alternate by depth (set depth & 1), because a bounce's
+ * continuation rays must survive the next bounce's dispatcher pass. */
+typedef struct rtamd_multibounce_lane {
+    float *cam_org;        /* [3] the eye, once per entry */
+    float *dir;            /* [3] primaries */
+    float *hits;           /* [4] primary records, then each bounce's continuation records */
+    float *position;       /* [3] G-buffer of the current bounce */
+    float *normal_mat;     /* [4] */
+    float *org[2], *shadow_dir[2], *reflect_dir[2], *ambient_dir[2];   /* [3] dispatcher targets */
+    float *shadow_hits;    /* [4] */
+} rtamd_multibounce_lane;
+
+/* Entries per lane buffer; primaries per sample (the shard's pixels inside the frame). */
+uint64_t rtamd_multibounce_entries(const rtamd_multibounce_desc *desc);
+uint64_t rtamd_multibounce_primary_rays(const rtamd_multibounce_desc *desc);
+int rtamd_multibounce_prepare_lane_device(rtamd_context *ctx, const rtamd_multibounce_desc *desc, const rtamd_multibounce_lane *lane);
+/* samples: n_samples (1..8) sample indices, sample k in lanes[k] (distinct lanes).  rays_traced: optional device counter
+ * that receives the number of traversals the call starts (NO_RAY entries excluded): primaries + per bounce one shadow ray
+ * and, up to the last depth, one continuation ray per pixel with a surface. */
+int rtamd_multibounce_sample_batch_device(rtamd_context *ctx, const rtamd_multibounce_desc *desc, const uint32_t *samples, uint32_t n_samples,
+                                          const rtamd_multibounce_lane *lanes, uint64_t *rays_traced);
+
 /* ---- multi-GPU frame assembly helpers -------------------------------------- */
 
 /* Number of 32x32 tiles a rank owns, maximised over ranks (the per-rank block

@@ -73,6 +73,24 @@ class DispatchDesc(ctypes.Structure):
     ]
 
 
+class MultiBounceDesc(ctypes.Structure):
+    _fields_ = [
+        ("width", ctypes.c_uint32), ("height", ctypes.c_uint32),
+        ("inv_proj_view", ctypes.c_float * 16), ("near_plane", ctypes.c_float), ("far_plane", ctypes.c_float),
+        ("cam_pos", ctypes.c_float * 3), ("light_pos", ctypes.c_float * 3),
+        ("has_normals", ctypes.c_uint32), ("max_depth", ctypes.c_uint32), ("noise_size", ctypes.c_uint32),
+        ("tile_rank", ctypes.c_uint32), ("tile_world", ctypes.c_uint32),
+    ]
+
+
+class MultiBounceLane(ctypes.Structure):
+    _fields_ = [
+        ("cam_org", ctypes.c_void_p), ("dir", ctypes.c_void_p), ("hits", ctypes.c_void_p), ("position", ctypes.c_void_p), ("normal_mat", ctypes.c_void_p),
+        ("org", ctypes.c_void_p * 2), ("shadow_dir", ctypes.c_void_p * 2), ("reflect_dir", ctypes.c_void_p * 2), ("ambient_dir", ctypes.c_void_p * 2),
+        ("shadow_hits", ctypes.c_void_p),
+    ]
+
+
 class TraceJob(ctypes.Structure):
     _fields_ = [("n", ctypes.c_uint64), ("org", ctypes.c_void_p), ("dir", ctypes.c_void_p), ("hits", ctypes.c_void_p)]
 
@@ -225,6 +243,13 @@ def device_lib():
         L.rtamd_set_kernel_variant.restype = ctypes.c_int
         L.rtamd_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
         L.rtamd_set_option.restype = ctypes.c_int
+        for name in ("rtamd_multibounce_entries", "rtamd_multibounce_primary_rays"):
+            getattr(L, name).argtypes = [ctypes.POINTER(MultiBounceDesc)]
+            getattr(L, name).restype = ctypes.c_uint64
+        L.rtamd_multibounce_prepare_lane_device.argtypes = [vp, ctypes.POINTER(MultiBounceDesc), ctypes.POINTER(MultiBounceLane)]
+        L.rtamd_multibounce_prepare_lane_device.restype = ctypes.c_int
+        L.rtamd_multibounce_sample_batch_device.argtypes = [vp, ctypes.POINTER(MultiBounceDesc), c_u32_p, ctypes.c_uint32, ctypes.POINTER(MultiBounceLane), vp]
+        L.rtamd_multibounce_sample_batch_device.restype = ctypes.c_int
         # one process, several GPUs (rtamd_multi_*)
         L.rtamd_multi_create.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(vp)]
         L.rtamd_multi_create.restype = ctypes.c_int

@@ -1333,3 +1333,5 @@ int rtamd_last_kernel_ms(rtamd_context *ctx, float *ms) {
 }
 
 }  // extern "C"
+
+#include "rtamd_chain.hip"

@@ -19,7 +19,12 @@ No colour comes out of this: the reference's consumer of these records (shader.f
 stub, so parity is pinned at ray level — every buffer of the chain against the CPU oracle
 (tests/test_gpu_multibounce.py).  There is no compute here: every step is a call into librtamd.so.
 """
+import ctypes
+
 import numpy as np
+
+from . import _ffi
+from .host import FAR, NEAR
 
 R2_G = 0.7548776662466927   # plastic-number constant of the R2 low-discrepancy sequence
 
@@ -51,6 +56,18 @@ class Lane:
         self.shadow_hits = f(4)
         self.cam_org = torch.tensor(cam_pos, dtype=torch.float32, device=dev).repeat(n, 1).contiguous()
         self.rays = torch.zeros((), dtype=torch.int64, device=dev)
+        # the buffers were made on torch's current stream; their first use is on this lane's (non-blocking) stream
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+
+    def c_lane(self):
+        """This lane's buffers as the C entry point takes them (rtamd_multibounce_lane)."""
+        ln = _ffi.MultiBounceLane()
+        ln.cam_org, ln.dir, ln.hits, ln.position, ln.normal_mat = (t.data_ptr() for t in (self.cam_org, self.dir, self.hits, self.pos, self.nm))
+        for k in range(2):
+            ln.org[k], ln.shadow_dir[k] = self.targets[k]["org"].data_ptr(), self.targets[k]["shadow"].data_ptr()
+            ln.reflect_dir[k], ln.ambient_dir[k] = self.targets[k]["reflect"].data_ptr(), self.targets[k]["ambient"].data_ptr()
+        ln.shadow_hits = self.shadow_hits.data_ptr()
+        return ln
 
 
 class MultiBounce:
@@ -118,17 +135,40 @@ class MultiBounce:
                     org, d = t["org"], cont
         return lane
 
+    def c_desc(self):
+        d = _ffi.MultiBounceDesc()
+        d.width, d.height = self.W, self.H
+        for i in range(16):
+            d.inv_proj_view[i] = float(self.inv[i])
+        d.near_plane, d.far_plane = NEAR, FAR
+        for i in range(3):
+            d.cam_pos[i], d.light_pos[i] = self.cam[i], self.light[i]
+        d.has_normals, d.max_depth, d.noise_size = self.has_n, self.depth, self.noise_size
+        d.tile_rank, d.tile_world = self.rank, self.world
+        return d
+
     def sample_batch(self, samples, lanes=None, records=None):
         """Several samples in lock step: sample samples[k] uses the buffers of lanes[k], everything is enqueued on lanes[0]'s
         stream, and the traversals of one stage — all samples' primaries, then per bounce all shadow and continuation rays —
         go out as ONE rtamd_trace_batch_device launch (up to 8 samples: 16 ray lists), so that the slow tail of a list runs
         beside the other lists' rays instead of beside an idle GPU.  Same buffers, bit for bit, as sample() gives each sample.
-        records: a list of dicts (one per sample), filled like sample()'s record."""
+        This is ONE call into the library (rtamd_multibounce_sample_batch_device, the chain as a C entry point).
+        records: a list of dicts (one per sample), filled like sample()'s record — intermediate buffers can only be copied
+        between the stages, so with records the same chain is issued stage by stage from here instead."""
         torch, tr, n, W, H = self.torch, self.tr, self.n, self.W, self.H
         lanes = list(lanes if lanes is not None else self.lanes[:len(samples)])
         if not 1 <= len(samples) <= 8 or len(lanes) != len(samples):
             raise ValueError("1..8 samples, one lane each")
         K = len(samples)
+        if records is None:
+            head = lanes[0]
+            with torch.cuda.stream(head.stream):
+                tr.set_stream(head.stream.cuda_stream)
+                desc = self.c_desc()
+                c_lanes = (_ffi.MultiBounceLane * K)(*[ln.c_lane() for ln in lanes])
+                c_samples = (ctypes.c_uint32 * K)(*[int(s) for s in samples])
+                tr._check(tr._lib.rtamd_multibounce_sample_batch_device(tr._h, ctypes.byref(desc), c_samples, K, c_lanes, ctypes.c_void_p(head.rays.data_ptr())))
+            return head
 
         def rec(k, depth, **bufs):
             if records is not None:

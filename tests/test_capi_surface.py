@@ -85,7 +85,7 @@ def test_ctypes_struct_layouts_equal_the_headers(tmp_path):
     from raytracer_amd import _ffi, renderer
     pairs = {"rtamd_scene_desc": _ffi.SceneDesc, "rtamd_frame_desc": _ffi.FrameDesc, "rtamd_frame_out": _ffi.FrameOut,
              "rtamd_dispatch_desc": _ffi.DispatchDesc, "rtamd_dispatch_out": _ffi.DispatchOut, "rtamd_scene_info": _ffi.SceneInfo,
-             "rtamd_trace_job": _ffi.TraceJob}
+             "rtamd_trace_job": _ffi.TraceJob, "rtamd_multibounce_desc": _ffi.MultiBounceDesc, "rtamd_multibounce_lane": _ffi.MultiBounceLane}
     lines = []
     for cname, cls in pairs.items():
         lines.append(f'printf("{cname} %zu", sizeof({cname}));')

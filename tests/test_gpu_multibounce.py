@@ -254,3 +254,55 @@ def test_samples_in_lock_step_equal_samples_one_by_one(tracer, atrium_scene):
             assert mb.rays_traced() == batch_rays
     finally:
         tracer.set_stream(0)
+
+
+def test_chain_as_one_c_call_equals_oracle_and_stage_by_stage(tracer, oracle_a, atrium_scene):
+    """rtamd_multibounce_sample_batch_device — the whole chain as ONE C entry point (what a non-Python host calls) — leaves in
+    the lanes' buffers, for max_depth 1, 2 and 3, exactly what the CPU oracle's chain holds at that point (so every buffer of
+    every depth is compared: a run of depth d ends with depth d's G-buffer, targets and shadow records and depth d-1's
+    continuation records), counts the traversals it starts, and prepares a lane's eye array itself."""
+    import ctypes
+    import torch
+    from raytracer_amd import _ffi
+    sc, cam, noise = atrium_scene
+    w, h = 240, 135
+    n = w * h
+    camera = _camera(cam, w, h)
+    inv = np.asarray(camera.inv_proj_view(), np.float32).reshape(16)
+    tracer.upload_scene(sc)
+    tracer.upload_noise_texture(noise)
+    samples = [0, 3, 6]
+    try:
+        want = {s: _oracle_chain(oracle_a, sc, noise, w, h, inv, camera.position, s, DEPTH) for s in samples}
+        for depth in (1, 2, 3):
+            mb = MultiBounce(tracer, w, h, inv, camera.position, LIGHT, True, depth=depth, lanes=len(samples))
+            for ln in mb.lanes:          # the library fills the eye array itself (rtamd_multibounce_prepare_lane_device)
+                ln.cam_org.fill_(-1.0)
+            torch.cuda.synchronize()
+            desc = mb.c_desc()
+            assert tracer._lib.rtamd_multibounce_entries(ctypes.byref(desc)) == n == tracer._lib.rtamd_multibounce_primary_rays(ctypes.byref(desc))
+            tracer.set_stream(mb.lanes[0].stream.cuda_stream)
+            for ln in mb.lanes:
+                c = ln.c_lane()
+                tracer._check(tracer._lib.rtamd_multibounce_prepare_lane_device(tracer._h, ctypes.byref(desc), ctypes.byref(c)))
+            mb.sample_batch(samples)
+            mb.synchronize()
+            rays = 0
+            for k, s in enumerate(samples):
+                ln, o = mb.lanes[k], want[s]
+                t = ln.targets[depth & 1]
+                got = {"position": ln.pos, "normal_mat": ln.nm, "org": t["org"], "shadow_dir": t["shadow"], "reflect_dir": t["reflect"],
+                       "ambient_dir": t["ambient"], "shadow_hits": ln.shadow_hits}
+                for key, buf in got.items():
+                    # a deeper oracle chain's buffers of depth d do not depend on max_depth, except that the last depth has no continuation
+                    assert np.array_equal(bits(buf.cpu().numpy()), bits(o[(depth, key)])), (depth, s, key)
+                prev = o[(0, "hits")] if depth == 1 else o[(depth - 1, "cont_hits")]
+                assert np.array_equal(bits(ln.hits.cpu().numpy()), bits(prev)), (depth, s, "hits")
+                assert np.array_equal(bits(ln.dir.cpu().numpy()), bits(o[(0, "dir")])), (depth, s, "dir")
+                rays += n
+                for d in range(1, depth + 1):
+                    surfaces = int((o[(d, "normal_mat")][:, 3] != MISS).sum())
+                    rays += surfaces * (2 if d < depth else 1)
+            assert mb.rays_traced() == rays
+    finally:
+        tracer.set_stream(0)

@@ -24,9 +24,10 @@ ap.add_argument("--width", type=int, default=3840)
 ap.add_argument("--height", type=int, default=2160)
 ap.add_argument("--depth", type=int, default=3)
 ap.add_argument("--gpus", type=int, default=1)
-ap.add_argument("--batch", type=int, default=-1, help="samples in lock step per rtamd_trace_batch_device launch (1..8); 0: one sample per lane, "
-                                                      "a launch per traversal (MultiBounce.sample); -1 = auto: 0 for the whole frame on one GPU "
-                                                      "(measured equal: 6.95 vs 7.02 Grays/s), 8 for a tile share (a 1/8 share: 1.10 -> 0.87 ms per sample frame)")
+ap.add_argument("--batch", type=int, default=-1, help="samples in lock step per call of the chain's C entry point (rtamd_multibounce_sample_batch_device, "
+                                                      "1..8: every stage's traversals of those samples are ONE rtamd_trace_batch_device launch); 0: the chain issued "
+                                                      "from Python, one sample per lane, a launch per traversal (MultiBounce.sample); -1 = auto: 8 (for the whole frame "
+                                                      "on one GPU both measure the same, 6.95 vs 7.02 Grays/s; a 1/8 tile share: 1.10 -> 0.87 ms per sample frame)")
 ap.add_argument("--groups", type=int, default=2, help="with --batch: batches in flight (streams)")
 ap.add_argument("--share-of", type=int, default=0, help="one process, one GPU: trace only rank 0's tile share of a split over that many ranks "
                                                          "(what one rank of an N-GPU run has to do; for scaling expectations)")
@@ -48,7 +49,7 @@ if args.share_of > 1 and world == 1:
 else:
     world_for_tiles, rank_for_tiles = world, rank
 if args.batch < 0:
-    args.batch = 8 if world_for_tiles > 1 else 0
+    args.batch = 8
 model, camera, _, _, tex = bench.build_workload("atrium_1080p")
 camera.aspect = W / H
 sc = model.scene_arrays()
@@ -101,5 +102,6 @@ print(json.dumps({"metric": "Mrays/s", "value": round(rays / dt / 1e6, 1), "unit
                   "config": {"workload": f"C5: atrium {len(sc['triangles'])} triangles, {W}x{H}, {args.spp} spp, depth <= {args.depth}, "
                                          "primary + (shadow + mirror|ambient continuation) per bounce", "rays": rays,
                              "rays_per_pixel_sample": round(rays / (n * args.spp), 3), "samples_in_flight": len(mb.lanes), "samples_per_trace_launch": args.batch or 1,
+                             "chain": "rtamd_multibounce_sample_batch_device (C entry point)" if args.batch else "issued call by call from raytracer_amd/multibounce.py",
                              "parallelism": f"tiles{world}" if world > 1 else (f"rank 0's share of tiles{args.share_of}, alone on one GPU" if args.share_of > 1 else "single")},
                   "seconds": round(dt, 4), "ms_per_sample_frame": round(dt / args.spp * 1e3, 3), "data": "synthetic", "dtype": "f32"}))
