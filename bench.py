@@ -190,6 +190,8 @@ def main():
                     help="N > 1: what crosses xGMI. rgba8 (default) = the display pass's 8-bit back buffer (util/display.frag) that "
                          "every rank produces from its RGBA32F share; f32 = the RGBA32F shares themselves: 33 MB per 1080p frame, "
                          "i.e. 138 GB/s at this frame rate — more than an xGMI link carries")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="rtamd_set_option on the context before anything is launched (A/B runs; repeatable); recorded in config.options")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extra measurements after the timed region (one frame at a time, non-overlapping batches): "
@@ -234,6 +236,9 @@ def main():
 
     tracer = HipRayTracer(local_rank)
     tracer.set_kernel_variant(args.variant)
+    for kv in args.option:
+        name, _, value = kv.partition("=")
+        tracer.set_option(name, int(value))
     tracer.upload_scene(sc)
     for slot, t in enumerate(tex):
         if t is not None:
@@ -573,7 +578,7 @@ def main():
                                f"{W}x{H}, 1 spp, primary + sun shadow ray + shading (fused ray_trace_and_shade semantics)",
                    "rays_per_frame": rays_per_frame, "primary_rays": n_primary_all, "shadow_rays": n_shadow_all,
                    "parallelism": f"tiles{world}" if world > 1 else "single", "kernel_variant": args.variant,
-                   "frames_per_launch": B, "streams": S,
+                   "frames_per_launch": B, "streams": S, **({"options": args.option} if args.option else {}),
                    **({"gather_format": args.gather_format, "rccl_ranks": comm["ranks"] if comm["backend"] == "nccl" else 0,
                        "collective_backend": comm["backend"], "gather_ms_per_frame": comm.get("gather_ms_per_frame"),
                        "assemble_ms_per_frame": comm.get("assemble_ms_per_frame"), "gather_bytes_per_peer_per_frame": comm.get("bytes_per_peer_per_frame"),

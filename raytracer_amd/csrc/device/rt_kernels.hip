@@ -137,6 +137,9 @@ struct JobParams {
     uint32_t queue_block;         // consecutive schedule positions a queue owns per turn
     uint32_t *spill;              // k_persistent: [wave slot][spill_wave_words / 64 entries][64] stack overflow area
     uint32_t spill_wave_words;    // u32 words per wave slot of `spill` (SPILL_STACK_ENTRIES * 64 for the context's own areas)
+    // Leaves are released when min(leaf_thresh, max(1, busy lanes * leaf_frac16 / 16)) lanes wait at one (0: leaf_thresh alone):
+    // a wave with few rays left must not make a lane at a leaf wait for a count that the others can hardly reach.
+    uint32_t leaf_frac16;
     // batch of frames in ONE launch (k_persistent, fused mode): item i belongs to frame i / items_per_frame; frame f's rays,
     // camera and outputs are frames[f] (the fields above are not used then).  n_frames == 1: the fields above, as ever.
     // batch of ray lists in ONE launch (trace mode): job j owns items job_item_begin[j] .. job_item_begin[j + 1] - 1; its ray list
@@ -850,7 +853,15 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
         // ---- traverse until too few lanes are still busy ----
         const uint32_t thresh = drained ? 1u : dyn_thresh;
         for (;;) {
-            if ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(tr.cur != REF_NONE)) < thresh) break;
+            const uint32_t n_busy = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(tr.cur != REF_NONE));
+            if (n_busy < thresh) break;
+            // this round's leaf-release count: leaf_thresh, or less when few lanes are busy (JobParams::leaf_frac16)
+            uint32_t leaf_eff = p.leaf_thresh;
+            if (p.leaf_frac16) {
+                uint32_t f = (n_busy * p.leaf_frac16) >> 4;
+                f = f < 1u ? 1u : f;
+                leaf_eff = f < leaf_eff ? f : leaf_eff;
+            }
 #ifdef RTAMD_EXP_STAMPS
             const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -873,7 +884,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                     const unsigned long long m_in = __builtin_amdgcn_ballot_w64(in);
                     if (!m_in) break;
                     const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64((int32_t)tr.cur < 0);
-                    if ((uint32_t)__popcll(m_leaf) >= p.leaf_thresh) break;
+                    if ((uint32_t)__popcll(m_leaf) >= leaf_eff) break;
 #ifdef RTAMD_EXP_STAMPS
                     stamp_inner++; stamp_inner_lanes += __popcll(m_in);
                     {

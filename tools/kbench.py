@@ -3,7 +3,7 @@
 interleaved rounds in one process per library, kernel time from HIP events.
 Usage: tools/kbench.py [--workload W] [--rounds N] arm [arm ...]
   arm = name[:key=value[,key=value...]]   keys: variant, dyn_thresh, num_queues, leaf_thresh, queue_stride, queue_block,
-        blocks (max_blocks_per_cu), anyhit, mode(fused|trace|incoherent)
+        blocks (max_blocks_per_cu), anyhit, lfrac (leaf_frac16), mode(fused|trace|incoherent)
 Libraries: RTAMD_DEVICE_LIB env (one process = one library)."""
 import argparse
 import json
@@ -52,6 +52,7 @@ def main():
         arms.append((name, opts))
     res = {name: [] for name, _ in arms}
     coh = {}
+    ref_out = {}
     import time
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.inflight))]
     outs = [torch.zeros((n, 4), dtype=torch.float32, device=dev) for _ in streams]
@@ -67,6 +68,7 @@ def main():
             tr.set_option("max_blocks_per_cu", int(o.get("blocks", 0)))
             tr.set_option("queue_block", int(o.get("queue_block", 256 if o.get("mode", "fused") == "fused" else 1)))
             tr.set_option("shadow_anyhit", int(o.get("anyhit", 1)))
+            tr.set_option("leaf_frac16", int(o.get("lfrac", 8)))
             mode = o.get("mode", "fused")
             if args.inflight > 1:
                 for rep in range(2):
@@ -90,6 +92,12 @@ def main():
                 else:
                     tr.trace_device(n, d_org.data_ptr(), d_dir_sh.data_ptr(), d_hits.data_ptr())
             ms = tr.last_kernel_ms()
+            # every arm must produce the bits of the first arm of its mode (results never depend on scheduling)
+            out_now = (d_rgba if mode == "fused" else d_hits).view(torch.int32)
+            if mode not in ref_out:
+                ref_out[mode] = out_now.clone()
+            elif not torch.equal(ref_out[mode], out_now):
+                raise SystemExit(f"arm {name}: output differs from the first {mode} arm's ({int((ref_out[mode] != out_now).any(1).sum())} pixels)")
             if r >= 2:
                 res[name].append(ms)
             coh[name] = tr.last_launch_coherence() if int(o.get("variant", 0)) == 0 else (-1.0, -1.0, 0)
