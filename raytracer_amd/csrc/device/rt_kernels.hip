@@ -137,7 +137,7 @@ struct JobParams {
     uint32_t queue_block;         // consecutive schedule positions a queue owns per turn
     uint32_t *spill;              // k_persistent: [wave slot][spill_wave_words / 64 entries][64] stack overflow area
     uint32_t spill_wave_words;    // u32 words per wave slot of `spill` (SPILL_STACK_ENTRIES * 64 for the context's own areas)
-    // Leaves are released when min(leaf_thresh, max(1, busy lanes * leaf_frac16 / 16)) lanes wait at one (0: leaf_thresh alone):
+    // Leaves are released when min(leaf_thresh, max(1, busy lanes * leaf_frac16 / 16)) lanes wait at one (the host passes 1024 for "off"):
     // a wave with few rays left must not make a lane at a leaf wait for a count that the others can hardly reach.
     uint32_t leaf_frac16;
     // batch of frames in ONE launch (k_persistent, fused mode): item i belongs to frame i / items_per_frame; frame f's rays,
@@ -853,15 +853,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
         // ---- traverse until too few lanes are still busy ----
         const uint32_t thresh = drained ? 1u : dyn_thresh;
         for (;;) {
-            const uint32_t n_busy = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(tr.cur != REF_NONE));
-            if (n_busy < thresh) break;
-            // this round's leaf-release count: leaf_thresh, or less when few lanes are busy (JobParams::leaf_frac16)
-            uint32_t leaf_eff = p.leaf_thresh;
-            if (p.leaf_frac16) {
-                uint32_t f = (n_busy * p.leaf_frac16) >> 4;
-                f = f < 1u ? 1u : f;
-                leaf_eff = f < leaf_eff ? f : leaf_eff;
-            }
+            if ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(tr.cur != REF_NONE)) < thresh) break;
 #ifdef RTAMD_EXP_STAMPS
             const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -874,6 +866,12 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
             // octant's slab_sel: same bits, 12 fewer VALU per visit.  phase bits 2..5 = 8 | octant.
             const uint32_t my_oct = (phase >> 2) & 15u;
             const unsigned long long m_busy = __builtin_amdgcn_ballot_w64(tr.cur != REF_NONE);
+            // This round's leaf-release count: leaf_thresh, or fewer when few lanes are busy (JobParams::leaf_frac16).  (Written here, from
+            // m_busy: the same count taken from the loop head's ballot made the register allocator's other choice -- 61 instead of 64
+            // VGPRs, equally spill-free, and 12-23 % slower on incoherent rays, profiles/r03_ab_leaf_release_rule.txt.)
+            uint32_t leaf_eff = ((uint32_t)__popcll(m_busy) * p.leaf_frac16) >> 4;
+            leaf_eff = leaf_eff < 1u ? 1u : leaf_eff;
+            leaf_eff = leaf_eff < p.leaf_thresh ? leaf_eff : p.leaf_thresh;
             const uint32_t oct0 = m_busy ? __builtin_amdgcn_readlane(my_oct, (int)__builtin_ctzll(m_busy)) : 0u;
             const bool oct_wave = (oct0 & 8u) && __builtin_amdgcn_ballot_w64(tr.cur != REF_NONE && my_oct != oct0) == 0ull;
             auto inner_loop = [&](auto pos_tag) __attribute__((always_inline)) {

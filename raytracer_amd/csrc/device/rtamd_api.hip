@@ -228,7 +228,7 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     p.dyn_incoherent = ctx->dyn_incoherent;
     p.stats_prev = nullptr; p.stats_cur = nullptr;
     p.leaf_thresh = ctx->leaf_thresh;
-    p.leaf_frac16 = ctx->leaf_frac16;
+    p.leaf_frac16 = ctx->leaf_frac16 ? ctx->leaf_frac16 : 1024u;   // 0 = off: 64 busy lanes * 1024 / 16 is beyond any leaf_thresh
     p.shadow_anyhit = ctx->shadow_anyhit ? 1u : 0u;
     p.tex_filter8 = ctx->tex_filter8 ? 1u : 0u;
     p.queue_stride = ctx->queue_stride; p.queue_block = mode == MODE_FUSED ? ctx->queue_block_fused : ctx->queue_block_trace;
@@ -979,7 +979,7 @@ int rtamd_render_device_static(rtamd_context *ctx, const rtamd_frame_desc *desc,
     p.dyn_thresh = ctx->dyn_thresh_fused; p.dyn_auto = 0; p.dyn_incoherent = ctx->dyn_incoherent;
     p.stats_prev = nullptr; p.stats_cur = nullptr;   // no coherence feedback: the re-fill threshold is the context's fixed one
     p.leaf_thresh = ctx->leaf_thresh;
-    p.leaf_frac16 = ctx->leaf_frac16;
+    p.leaf_frac16 = ctx->leaf_frac16 ? ctx->leaf_frac16 : 1024u;   // 0 = off: 64 busy lanes * 1024 / 16 is beyond any leaf_thresh
     p.shadow_anyhit = ctx->shadow_anyhit ? 1u : 0u;
     p.tex_filter8 = ctx->tex_filter8 ? 1u : 0u;
     p.spill = ptr + STATIC_QUEUE_WORDS;

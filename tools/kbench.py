@@ -68,7 +68,10 @@ def main():
             tr.set_option("max_blocks_per_cu", int(o.get("blocks", 0)))
             tr.set_option("queue_block", int(o.get("queue_block", 256 if o.get("mode", "fused") == "fused" else 1)))
             tr.set_option("shadow_anyhit", int(o.get("anyhit", 1)))
-            tr.set_option("leaf_frac16", int(o.get("lfrac", 8)))
+            try:
+                tr.set_option("leaf_frac16", int(o.get("lfrac", 8)))
+            except Exception:       # a library build from before the option existed (A/B against an older commit)
+                pass
             mode = o.get("mode", "fused")
             if args.inflight > 1:
                 for rep in range(2):
