@@ -506,10 +506,9 @@ int rtamd_set_kernel_variant(rtamd_context *ctx, int variant);
  *                       (camera rays, sun shadow rays), switches to 32 below that (triangle soups, bounces)
  *                       for 64 launches, then probes one launch at 1 again; the first launch uses 1;
  *  "leaf_thresh" 1..64  lanes waiting at a leaf are served once this many wait (64 = classic
- *                       while-while traversal, 1 = if-if);
- *  "leaf_frac16" 0..1024  ... or once that many 16ths of the wave's busy lanes wait, whichever is less (default 8 = half of them;
- *                       0 = leaf_thresh alone): a wave with few rays left does not make a lane at a leaf wait for a count the
- *                       others can hardly reach.  Per-lane order is untouched, so no result bit depends on it;
+ *                       while-while traversal, 1 = if-if), or once half of the wave's busy lanes wait, whichever is fewer (a wave
+ *                       with few rays left does not make a lane at a leaf wait for a count the others can hardly reach).
+ *                       Per-lane order is untouched, so no result bit depends on it;
  *  "num_queues" 1..32   work-queue counters (8 = one per XCD);
  *  "queue_stride" 1..4096  u32 words between the counters (default 64 = 256 B, one memory
  *                       channel each);

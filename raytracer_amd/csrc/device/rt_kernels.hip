@@ -137,9 +137,6 @@ struct JobParams {
     uint32_t queue_block;         // consecutive schedule positions a queue owns per turn
     uint32_t *spill;              // k_persistent: [wave slot][spill_wave_words / 64 entries][64] stack overflow area
     uint32_t spill_wave_words;    // u32 words per wave slot of `spill` (SPILL_STACK_ENTRIES * 64 for the context's own areas)
-    // Leaves are released when min(leaf_thresh, max(1, busy lanes * leaf_frac16 / 16)) lanes wait at one (the host passes 1024 for "off"):
-    // a wave with few rays left must not make a lane at a leaf wait for a count that the others can hardly reach.
-    uint32_t leaf_frac16;
     // batch of frames in ONE launch (k_persistent, fused mode): item i belongs to frame i / items_per_frame; frame f's rays,
     // camera and outputs are frames[f] (the fields above are not used then).  n_frames == 1: the fields above, as ever.
     // batch of ray lists in ONE launch (trace mode): job j owns items job_item_begin[j] .. job_item_begin[j + 1] - 1; its ray list
@@ -866,10 +863,11 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
             // octant's slab_sel: same bits, 12 fewer VALU per visit.  phase bits 2..5 = 8 | octant.
             const uint32_t my_oct = (phase >> 2) & 15u;
             const unsigned long long m_busy = __builtin_amdgcn_ballot_w64(tr.cur != REF_NONE);
-            // This round's leaf-release count: leaf_thresh, or fewer when few lanes are busy (JobParams::leaf_frac16).  (Written here, from
-            // m_busy: the same count taken from the loop head's ballot made the register allocator's other choice -- 61 instead of 64
-            // VGPRs, equally spill-free, and 12-23 % slower on incoherent rays, profiles/r03_ab_leaf_release_rule.txt.)
-            uint32_t leaf_eff = ((uint32_t)__popcll(m_busy) * p.leaf_frac16) >> 4;
+            // This round's leaf-release count: leaf_thresh, or half of the busy lanes when that is fewer -- a wave with few rays left must
+            // not make a lane at a leaf wait for a count the others can hardly reach.  (The form matters to the register allocator: the
+            // same count from the loop head's ballot gave 61 instead of 64 VGPRs, equally spill-free, and 12-23 % slower incoherent
+            // rays; a run-time fraction or shift instead of the constant one 1.4 % slower batches: profiles/r03_ab_leaf_release_rule.txt.)
+            uint32_t leaf_eff = (uint32_t)__popcll(m_busy) >> 1;
             leaf_eff = leaf_eff < 1u ? 1u : leaf_eff;
             leaf_eff = leaf_eff < p.leaf_thresh ? leaf_eff : p.leaf_thresh;
             const uint32_t oct0 = m_busy ? __builtin_amdgcn_readlane(my_oct, (int)__builtin_ctzll(m_busy)) : 0u;

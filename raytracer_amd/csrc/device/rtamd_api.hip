@@ -91,7 +91,6 @@ struct rtamd_context {
     uint32_t max_blocks_per_cu = 0;   // 0 = as many as fit (8 workgroups = 8 waves per SIMD)
     uint32_t queue_block_fused = 256, queue_block_trace = 1;   // measured: 256-item regions per XCD turn help camera frames 1.5 %, not ray lists
     uint32_t n_queues = 8;
-    uint32_t leaf_frac16 = 8;         // option "leaf_frac16": ... or when that many 16ths of the wave's busy lanes do (0: leaf_thresh alone)
 };
 
 namespace {
@@ -228,7 +227,6 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     p.dyn_incoherent = ctx->dyn_incoherent;
     p.stats_prev = nullptr; p.stats_cur = nullptr;
     p.leaf_thresh = ctx->leaf_thresh;
-    p.leaf_frac16 = ctx->leaf_frac16 ? ctx->leaf_frac16 : 1024u;   // 0 = off: 64 busy lanes * 1024 / 16 is beyond any leaf_thresh
     p.shadow_anyhit = ctx->shadow_anyhit ? 1u : 0u;
     p.tex_filter8 = ctx->tex_filter8 ? 1u : 0u;
     p.queue_stride = ctx->queue_stride; p.queue_block = mode == MODE_FUSED ? ctx->queue_block_fused : ctx->queue_block_trace;
@@ -537,9 +535,6 @@ int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value) {
     } else if (!std::strcmp(name, "max_blocks_per_cu")) {
         if (value < 0 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "max_blocks_per_cu must be 0..64");
         ctx->max_blocks_per_cu = (uint32_t)value;
-    } else if (!std::strcmp(name, "leaf_frac16")) {
-        if (value < 0 || value > 1024) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "leaf_frac16 must be 0..1024");
-        ctx->leaf_frac16 = (uint32_t)value;
     } else if (!std::strcmp(name, "validate_buffers")) {
         ctx->validate_buffers = value != 0;
     } else if (!std::strcmp(name, "launch_timing")) {
@@ -979,7 +974,6 @@ int rtamd_render_device_static(rtamd_context *ctx, const rtamd_frame_desc *desc,
     p.dyn_thresh = ctx->dyn_thresh_fused; p.dyn_auto = 0; p.dyn_incoherent = ctx->dyn_incoherent;
     p.stats_prev = nullptr; p.stats_cur = nullptr;   // no coherence feedback: the re-fill threshold is the context's fixed one
     p.leaf_thresh = ctx->leaf_thresh;
-    p.leaf_frac16 = ctx->leaf_frac16 ? ctx->leaf_frac16 : 1024u;   // 0 = off: 64 busy lanes * 1024 / 16 is beyond any leaf_thresh
     p.shadow_anyhit = ctx->shadow_anyhit ? 1u : 0u;
     p.tex_filter8 = ctx->tex_filter8 ? 1u : 0u;
     p.spill = ptr + STATIC_QUEUE_WORDS;

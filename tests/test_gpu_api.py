@@ -263,16 +263,16 @@ def test_full_size_atrium_properties(tracer, oracle_a, atrium):
     tracer.upload_texture(0, tex[0]); tracer.upload_texture(1, tex[1])
     inv = camera.inv_proj_view()
     ref = None
-    defaults = {"kernel_variant": 0, "dyn_thresh": 0, "leaf_thresh": 8, "leaf_frac16": 8, "num_queues": 8, "queue_stride": 64,
+    defaults = {"kernel_variant": 0, "dyn_thresh": 0, "leaf_thresh": 8, "num_queues": 8, "queue_stride": 64,
                 "max_blocks_per_cu": 0, "shadow_anyhit": 1, "queue_block": 256}
     try:
         tracer.set_option("shadow_anyhit", 0)   # reference-length shadow traversals: counters comparable with the oracle
         full = tracer.render(W, H, camera=(inv, camera.position), has_tex_coords=1, has_normals=1, want=("rgba", "hit_id", "hit_t", "counts"))
         tracer.set_option("shadow_anyhit", 1)
-        for opts in ({"kernel_variant": 1}, {"kernel_variant": 0, "dyn_thresh": 1, "leaf_thresh": 4, "num_queues": 8, "leaf_frac16": 0},
-                     {"kernel_variant": 0, "dyn_thresh": 40, "leaf_thresh": 64, "num_queues": 1, "queue_stride": 16, "leaf_frac16": 16},
-                     {"kernel_variant": 0, "dyn_thresh": 64, "leaf_thresh": 1, "num_queues": 3, "max_blocks_per_cu": 5, "queue_block": 7, "leaf_frac16": 3},
-                     {"kernel_variant": 0, "dyn_thresh": 1, "leaf_thresh": 24, "leaf_frac16": 1024},
+        for opts in ({"kernel_variant": 1}, {"kernel_variant": 0, "dyn_thresh": 1, "leaf_thresh": 4, "num_queues": 8},
+                     {"kernel_variant": 0, "dyn_thresh": 40, "leaf_thresh": 64, "num_queues": 1, "queue_stride": 16},
+                     {"kernel_variant": 0, "dyn_thresh": 64, "leaf_thresh": 1, "num_queues": 3, "max_blocks_per_cu": 5, "queue_block": 7},
+                     {"kernel_variant": 0, "dyn_thresh": 1, "leaf_thresh": 24},
                      {"kernel_variant": 0, "dyn_thresh": 1, "leaf_thresh": 8, "num_queues": 16, "max_blocks_per_cu": 0},
                      {"kernel_variant": 0, "dyn_thresh": 0}, {"kernel_variant": 0, "dyn_thresh": 0}):
             for k, v in opts.items():

@@ -3,7 +3,7 @@
 interleaved rounds in one process per library, kernel time from HIP events.
 Usage: tools/kbench.py [--workload W] [--rounds N] arm [arm ...]
   arm = name[:key=value[,key=value...]]   keys: variant, dyn_thresh, num_queues, leaf_thresh, queue_stride, queue_block,
-        blocks (max_blocks_per_cu), anyhit, lfrac (leaf_frac16), mode(fused|trace|incoherent)
+        blocks (max_blocks_per_cu), anyhit, mode(fused|trace|incoherent)
 Libraries: RTAMD_DEVICE_LIB env (one process = one library)."""
 import argparse
 import json
@@ -68,10 +68,6 @@ def main():
             tr.set_option("max_blocks_per_cu", int(o.get("blocks", 0)))
             tr.set_option("queue_block", int(o.get("queue_block", 256 if o.get("mode", "fused") == "fused" else 1)))
             tr.set_option("shadow_anyhit", int(o.get("anyhit", 1)))
-            try:
-                tr.set_option("leaf_frac16", int(o.get("lfrac", 8)))
-            except Exception:       # a library build from before the option existed (A/B against an older commit)
-                pass
             mode = o.get("mode", "fused")
             if args.inflight > 1:
                 for rep in range(2):

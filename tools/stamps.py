@@ -21,7 +21,6 @@ d_dir = torch.empty((n, 3), dtype=torch.float32, device=dev); tr.generate_rays_d
 d_org = torch.tensor(np.asarray(camera.position, np.float32), device=dev).repeat(n, 1).contiguous()
 d_rgba = torch.zeros((n, 4), dtype=torch.float32, device=dev)
 tr.set_option('leaf_thresh', 8)
-if os.environ.get('STAMPS_LEAF_FRAC16'): tr.set_option('leaf_frac16', int(os.environ['STAMPS_LEAF_FRAC16']))
 prev_dur = prev_ok = None
 for th, nq, ad, pr in ((1, 8, 0, 0),):
     tr.set_option("dyn_thresh", th); tr.set_option("num_queues", nq)
