@@ -256,6 +256,15 @@ typedef struct rtamd_trace_job {
 } rtamd_trace_job;
 int rtamd_trace_batch_device(rtamd_context *ctx, uint32_t n_jobs, const rtamd_trace_job *jobs);
 
+/* The same for ray lists that are IMAGES: list j holds one ray per pixel, in scan-line order with `width` rays per row
+ * (tile_world <= 1; jobs[j].n a multiple of width) or in the compact tile-major shard layout (tile_world > 1: whole 32x32
+ * tiles, row-major inside a tile; jobs[j].n a multiple of 1024; width is not used).  Which ray is traced with which is the
+ * only difference: a work item is an 8x8 pixel block of the image -- the fused shader's item shape -- instead of 64
+ * consecutive rays (a 64x1 strip of it), so that the rays of a wave stay together longer.  Records are bit for bit those of
+ * rtamd_trace_batch_device, in the same places.  This is how the ray_trace passes of src/main.rs:176-203 run on their
+ * full-screen targets; rtamd_multibounce_sample_batch_device uses it for every list.  1 <= n_jobs <= 16. */
+int rtamd_trace_image_batch_device(rtamd_context *ctx, uint32_t n_jobs, const rtamd_trace_job *jobs, uint32_t width, uint32_t tile_world);
+
 /* ---- ray generation: ray_trace/ray_create.frag:12 + util/quad-11.vert:8 ---- */
 
 /* dir_out: 3 floats per pixel, scan-line order, row 0 = bottom row. */

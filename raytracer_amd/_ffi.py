@@ -208,6 +208,9 @@ def device_lib():
             getattr(L, name).restype = ctypes.c_int
         L.rtamd_trace_batch_device.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(TraceJob)]
         L.rtamd_trace_batch_device.restype = ctypes.c_int
+        if hasattr(L, "rtamd_trace_image_batch_device"):      # (absent from older builds loaded through RTAMD_DEVICE_LIB for A/B runs)
+            L.rtamd_trace_image_batch_device.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(TraceJob), ctypes.c_uint32, ctypes.c_uint32]
+            L.rtamd_trace_image_batch_device.restype = ctypes.c_int
         for name in ("rtamd_generate_rays", "rtamd_generate_rays_device"):
             getattr(L, name).argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, c_float_p, ctypes.c_float, ctypes.c_float, vp]
             getattr(L, name).restype = ctypes.c_int

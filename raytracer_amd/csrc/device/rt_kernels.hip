@@ -132,7 +132,7 @@ struct JobParams {
     // stats_prev = what the previous launch of this mode on this stream measured (nullptr: none yet)
     const uint32_t *stats_prev;
     uint32_t *stats_cur;
-    uint32_t dyn_auto;            // 1: pick the lane re-fill threshold from stats_prev (coherent: 1, incoherent: dyn_incoherent)
+    uint32_t dyn_auto;            // 1: pick the lane re-fill threshold from stats_prev (coherent: 1, incoherent: dyn_incoherent); batches of ray lists: per wave and list
     uint32_t dyn_incoherent;
     uint32_t queue_block;         // consecutive schedule positions a queue owns per turn
     uint32_t *spill;              // k_persistent: [wave slot][spill_wave_words / 64 entries][64] stack overflow area
@@ -739,8 +739,15 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
     // different times (triangle soups, shuffled rays: 19-37 %), where re-filling below dyn_incoherent busy
     // lanes is 6-30 % faster.  The measure is only meaningful without re-fill, so a launch that re-fills
     // keeps doing so for 63 launches and then one launch probes again without.
+    // A batch of ray lists is different: coherent and incoherent lists sit side by side in ONE launch (config 5: shadow rays
+    // next to ambient bounces), and the launch before it held other kinds of lists.  There every wave decides for itself,
+    // list by list: it starts a list without re-fill and switches re-fill on for the rest of that list as soon as its own
+    // visits in it (at least 32) had under half of the lanes active.
     uint32_t dyn_thresh = p.dyn_thresh, dyn_age = 0;
-    if (p.dyn_auto && p.stats_prev) {
+    const bool per_list = MODE == MODE_TRACE && p.dyn_auto && p.n_frames > 1u;
+    uint32_t probe_job = 0xFFFFFFFFu, probe_inner = 0, probe_lanes = 0;
+    if (per_list) dyn_thresh = 1u;
+    else if (p.dyn_auto && p.stats_prev) {
         const uint32_t n = p.stats_prev[1], l = p.stats_prev[2], was = p.stats_prev[3] & 255u, age = p.stats_prev[3] >> 8;
         if (n >= 4096u && was != 0u) {
             if (was == 1u) dyn_thresh = (2ull * l < 64ull * n) ? p.dyn_incoherent : 1u;   // under 50 % of the lanes active per visit
@@ -780,6 +787,13 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
 #endif
                 if (item == 0xFFFFFFFFu) { drained = true; break; }
                 pool_item = item; pool_next = 0;
+                if (MODE == MODE_TRACE && per_list) {
+                    uint32_t job = 0;
+                    for (uint32_t k = 1; k < p.n_frames; k++) if (item >= p.job_item_begin[k]) job = k;
+                    if (job != probe_job) { probe_job = job; dyn_thresh = 1u; probe_inner = stat_inner; probe_lanes = stat_lanes; }
+                    else if (dyn_thresh == 1u && stat_inner - probe_inner >= 32u && 2u * (stat_lanes - probe_lanes) < 64u * (stat_inner - probe_inner))
+                        dyn_thresh = p.dyn_incoherent;
+                }
             }
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             const uint32_t avail = 64u - pool_next;
@@ -825,8 +839,25 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                         item_in_job = pool_item - p.job_item_begin[job];
                         j_dir = p.frames[job].dir; j_org = p.frames[job].org; j_hits = p.frames[job].rgba; j_rays = p.frames[job].n_rays;
                     }
-                    const uint64_t ri = (uint64_t)item_in_job * 64u + l;
-                    if (ri < j_rays) {
+                    // Which ray of the list this lane takes.  A plain list: 64 consecutive rays per item.  A list that is an image in
+                    // scan-line order (p.width) or in the compact tile-major layout (p.tiles_x): an 8x8 pixel block per item, the fused
+                    // kernel's item shape -- the same rays, grouped so that a wave's rays stay together longer (config 5's lists at
+                    // 3840x2160: -9 % over a sample's twelve lists, -20 % on the coherent ones, profiles/r03_ab_block_order.txt).
+                    // An item is eight runs of eight rays: first ray `base`, `stride` rays from run to run, `cols` rays per run that exist
+                    // (all wave-uniform); 64 consecutive rays are the case stride = 8.
+                    uint32_t base = item_in_job * 64u, stride = 8u, cols = 8u;
+                    if (p.tiles_x) {
+                        const uint32_t sub = item_in_job & 15u;
+                        base = (item_in_job >> 4) * RTAMD_TILE_PIXELS + (sub >> 2) * 256u + (sub & 3u) * 8u; stride = 32u;
+                    } else if (p.width) {
+                        // by = item / blocks per row, as a multiplication (p.height carries ceil(2^32 / blocks per row); the host checked its range)
+                        const uint32_t bpr = (p.width + 7u) >> 3, by = __umulhi(item_in_job, p.height), bx = item_in_job - by * bpr;
+                        base = by * 8u * p.width + bx * 8u; stride = p.width;
+                        cols = p.width - bx * 8u; cols = cols < 8u ? cols : 8u;
+                    }
+                    const uint64_t ri = (uint64_t)base + (l >> 3) * stride + (l & 7u);
+                    const bool has_ray = (l & 7u) < cols;
+                    if (has_ray && ri < j_rays) {
                         const float *d = j_dir + 3 * ri, *o = j_org + 3 * ri;
                         out_index = (uint32_t)ri | (job << BATCH_FRAME_SHIFT);      // job is 0 unless this is a batch
                         nbox = 0; ntri = 0;
@@ -981,7 +1012,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
         atomicAdd(&p.stats_cur[0], stat_uniform);
         atomicAdd(&p.stats_cur[1], stat_inner);
         atomicAdd(&p.stats_cur[2], stat_lanes);
-        p.stats_cur[3] = dyn_thresh | (dyn_age << 8);
+        p.stats_cur[3] = (per_list ? 1u : dyn_thresh) | (dyn_age << 8);     // (a batch of lists reports 1: its waves chose list by list)
     }
 #ifdef RTAMD_EXP_STAMPS
     if (lane == 0 && p.stamps) {

@@ -2,6 +2,7 @@
 // conversion, kernel launches.  gfx950 only; no CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1077,17 +1078,38 @@ int rtamd_trace_device(rtamd_context *ctx, uint64_t n, const float *org, const f
     return launch_main(ctx, MODE_TRACE, false, p);
 }
 
-int rtamd_trace_batch_device(rtamd_context *ctx, uint32_t n_jobs, const rtamd_trace_job *jobs) {
+namespace {
+
+// Work items of a ray list of n rays: 64 consecutive rays each, or -- for a list that is an image -- 8x8 pixel blocks
+// (layout 1: scan-line order, `width` pixels per row; layout 2: the compact tile-major layout, 16 blocks per 32x32 tile).
+uint32_t trace_items(uint64_t n, int layout, uint32_t width) {
+    if (layout == 1) { const uint64_t rows = (n + width - 1) / width; return (uint32_t)(((uint64_t)(width + 7) / 8) * ((rows + 7) / 8)); }
+    if (layout == 2) return (uint32_t)((n + RTAMD_TILE_PIXELS - 1) / RTAMD_TILE_PIXELS) * 16u;
+    return (uint32_t)((n + 63) / 64);
+}
+
+int trace_batch(rtamd_context *ctx, uint32_t n_jobs, const rtamd_trace_job *jobs, int layout, uint32_t width) {
     if (!ctx) return RTAMD_ERR_INVALID_ARGUMENT;
     if (!ctx->has_scene) return fail(ctx, RTAMD_ERR_NO_SCENE, "no scene uploaded");
     if (n_jobs == 0 || n_jobs > RTAMD_MAX_BATCH_FRAMES) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "a batch holds 1..%d ray lists, not %u", RTAMD_MAX_BATCH_FRAMES, n_jobs);
     if (!jobs) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "jobs is NULL");
+    if (layout == 1 && width == 0) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "an image in scan-line order needs its width");
     for (uint32_t j = 0; j < n_jobs; j++) {
         if (jobs[j].n && (!jobs[j].org || !jobs[j].dir || !jobs[j].hits)) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "job %u: org / dir / hits is NULL", j);
-        if (jobs[j].n >= (1ull << BATCH_FRAME_SHIFT) && n_jobs > 1) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "job %u: the ray lists of a batch are limited to 2^%u - 1 rays", j, BATCH_FRAME_SHIFT);
+        if (jobs[j].n >= (1ull << BATCH_FRAME_SHIFT) && (n_jobs > 1 || layout != 0))
+            return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "job %u: the ray lists of a batch are limited to 2^%u - 1 rays", j, BATCH_FRAME_SHIFT);
+        if (layout == 1 && jobs[j].n % width) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "job %u: %llu rays are not rows of %u pixels", j, (unsigned long long)jobs[j].n, width);
+        if (layout == 2 && jobs[j].n % RTAMD_TILE_PIXELS) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "job %u: %llu rays are not whole 32x32 tiles", j, (unsigned long long)jobs[j].n);
+    }
+    if (layout == 1) {
+        // images of at most 8 columns, or so large that the kernel's division by multiplication would leave its exact range: the same
+        // rays as plain lists (only the grouping into work items differs, never a record)
+        uint64_t most = 0;
+        for (uint32_t j = 0; j < n_jobs; j++) most = std::max<uint64_t>(most, trace_items(jobs[j].n, 1, width));
+        if (width <= 8 || most * ((width + 7u) / 8u) >= (1ull << 32)) layout = 0;
     }
     int rc;
-    if (n_jobs == 1 || ctx->variant != 0) {      // the A/B baseline kernel has no batch form: list by list
+    if (ctx->variant != 0 || (n_jobs == 1 && layout == 0)) {      // the A/B baseline kernel has neither a batch form nor block items: list by list
         for (uint32_t j = 0; j < n_jobs; j++) if ((rc = rtamd_trace_device(ctx, jobs[j].n, jobs[j].org, jobs[j].dir, jobs[j].hits))) return rc;
         return RTAMD_OK;
     }
@@ -1097,18 +1119,33 @@ int rtamd_trace_batch_device(rtamd_context *ctx, uint32_t n_jobs, const rtamd_tr
     std::memset(&p, 0, sizeof p);
     p.world = 1;
     p.n_frames = n_jobs;
+    p.width = layout == 1 ? width : 0u;
+    p.tiles_x = layout == 2 ? 1u : 0u;
+    if (layout == 1) {      // the kernel divides item indices by the blocks per row with one multiplication: ceil(2^32 / d) is exact for items < 2^32 / d
+        const uint32_t bpr = (width + 7u) / 8u;
+        p.height = (uint32_t)(((1ull << 32) + bpr - 1) / bpr);
+    }
     uint32_t items = 0;
     for (uint32_t j = 0; j < n_jobs; j++) {
         const uint64_t n = jobs[j].n;
         if ((rc = check_range(ctx, jobs[j].org, n * 12, "org")) || (rc = check_range(ctx, jobs[j].dir, n * 12, "dir")) || (rc = check_range(ctx, jobs[j].hits, n * 16, "hits"))) return rc;
         p.job_item_begin[j] = items;
-        items += (uint32_t)((n + 63) / 64);          // <= 16 * 2^22 items
+        items += trace_items(n, layout, width);          // <= 16 * 2^22 items
         FrameIO &io = p.frames[j];
         io.org = jobs[j].org; io.dir = jobs[j].dir; io.rgba = jobs[j].hits; io.n_rays = (uint32_t)n;
     }
     for (uint32_t j = n_jobs; j <= (uint32_t)MAX_BATCH_FRAMES; j++) p.job_item_begin[j] = items;
     p.n_items = items;
+    if (n_jobs == 1) { p.dir = jobs[0].dir; p.org = jobs[0].org; p.hits = jobs[0].hits; p.n_rays = jobs[0].n; }    // one list: the kernel's plain arguments
     return launch_main(ctx, MODE_TRACE, false, p);     // n_items == 0 (every list empty): nothing to launch
+}
+
+}  // namespace
+
+int rtamd_trace_batch_device(rtamd_context *ctx, uint32_t n_jobs, const rtamd_trace_job *jobs) { return trace_batch(ctx, n_jobs, jobs, 0, 0); }
+
+int rtamd_trace_image_batch_device(rtamd_context *ctx, uint32_t n_jobs, const rtamd_trace_job *jobs, uint32_t width, uint32_t tile_world) {
+    return trace_batch(ctx, n_jobs, jobs, tile_world > 1 ? 2 : 1, width);
 }
 
 int rtamd_trace(rtamd_context *ctx, uint64_t n, const float *org, const float *dir, float *hits) {

@@ -115,7 +115,7 @@ int rtamd_multibounce_sample_batch_device(rtamd_context *ctx, const rtamd_multib
         if ((rc = rtamd_generate_rays_tiles_device(ctx, W, H, desc->inv_proj_view, desc->near_plane, desc->far_plane, ox, oy, sh.rank, sh.world, lanes[k].dir))) return rc;
         jobs[k].n = n; jobs[k].org = lanes[k].cam_org; jobs[k].dir = lanes[k].dir; jobs[k].hits = lanes[k].hits;
     }
-    if ((rc = rtamd_trace_batch_device(ctx, n_samples, jobs))) return rc;
+    if ((rc = rtamd_trace_image_batch_device(ctx, n_samples, jobs, W, sh.world))) return rc;
     if (rays_traced) {
         if ((uintptr_t)rays_traced & 7u) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "multibounce: rays_traced must be 8-byte aligned");
         DeviceScope dev_scope;
@@ -169,7 +169,7 @@ int rtamd_multibounce_sample_batch_device(rtamd_context *ctx, const rtamd_multib
                 n_jobs++;
                 cur_org[k] = ln.org[t]; cur_dir[k] = cont;
             }
-        if ((rc = rtamd_trace_batch_device(ctx, n_jobs, jobs))) return rc;
+        if ((rc = rtamd_trace_image_batch_device(ctx, n_jobs, jobs, W, sh.world))) return rc;
     }
     return RTAMD_OK;
 }

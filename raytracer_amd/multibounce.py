@@ -6,13 +6,13 @@ rtamd_surface_from_hits_device turning a bounce's hit records into the next G-bu
 fills it with its rasteriser, src/main.rs:127-140).  Per sample s of a pixel:
 
     jittered primary  rtamd_generate_rays_tiles_device  (R2 sequence; sample 0 = the pixel centre)
-    closest hit       rtamd_trace_device                           (ray_trace.frag:131-143)
+    closest hit       rtamd_trace_image_batch_device               (ray_trace.frag:131-143; 8x8-pixel work items)
     for depth 1..D:
         surface       rtamd_surface_from_hits_device               (position, normal | material)
         dispatcher    rtamd_dispatch_rays_device                   (ray_dispatcher.frag:26-41)
-        shadow ray    rtamd_trace_device(org, shadow_dir)          -> shadow_hits
-        continuation  rtamd_trace_device(org, reflect_dir)  for even s   (mirror, :41)
-                      rtamd_trace_device(org, ambient_dir)  for odd s    (normalize(n + noise*2-1), :42)
+        shadow ray    ... (org, shadow_dir)                        -> shadow_hits
+        continuation  ... (org, reflect_dir)  for even s           (mirror, :41)
+                      ... (org, ambient_dir)  for odd s            (normalize(n + noise*2-1), :42)
                       (not after the last depth)
 
 No colour comes out of this: the reference's consumer of these records (shader.frag:120-124) is a TODO
@@ -110,7 +110,7 @@ class MultiBounce:
             tr.set_stream(lane.stream.cuda_stream)
             ox, oy = sample_offset(s)
             tr.generate_rays_tiles_device(W, H, self.inv, ox, oy, self.rank, self.world, lane.dir.data_ptr())
-            tr.trace_device(n, lane.cam_org.data_ptr(), lane.dir.data_ptr(), lane.hits.data_ptr())
+            tr.trace_image_batch_device([(n, lane.cam_org.data_ptr(), lane.dir.data_ptr(), lane.hits.data_ptr())], W, self.world)
             lane.rays += self.n_primary
             rec(0, dir=lane.dir, hits=lane.hits)
             org, d = lane.cam_org, lane.dir
@@ -122,14 +122,14 @@ class MultiBounce:
                                         shadow_dir_ptr=t["shadow"].data_ptr(), reflect_dir_ptr=t["reflect"].data_ptr(), ambient_dir_ptr=t["ambient"].data_ptr(),
                                         tile_rank=self.rank, tile_world=self.world)
                 surfaces = (lane.nm[:, 3] != 1e30).sum()
-                tr.trace_device(n, t["org"].data_ptr(), t["shadow"].data_ptr(), lane.shadow_hits.data_ptr())
+                tr.trace_image_batch_device([(n, t["org"].data_ptr(), t["shadow"].data_ptr(), lane.shadow_hits.data_ptr())], W, self.world)
                 lane.rays += surfaces
                 rec(depth, position=lane.pos, normal_mat=lane.nm, org=t["org"], shadow_dir=t["shadow"], reflect_dir=t["reflect"],
                     ambient_dir=t["ambient"], shadow_hits=lane.shadow_hits)
                 if depth < self.depth:
                     cont = t["reflect"] if s % 2 == 0 else t["ambient"]
                     # hits is read by nothing else from here on: the continuation's records replace the previous bounce's
-                    tr.trace_device(n, t["org"].data_ptr(), cont.data_ptr(), lane.hits.data_ptr())
+                    tr.trace_image_batch_device([(n, t["org"].data_ptr(), cont.data_ptr(), lane.hits.data_ptr())], W, self.world)
                     lane.rays += surfaces
                     rec(depth, cont_hits=lane.hits)
                     org, d = t["org"], cont
@@ -150,7 +150,7 @@ class MultiBounce:
     def sample_batch(self, samples, lanes=None, records=None):
         """Several samples in lock step: sample samples[k] uses the buffers of lanes[k], everything is enqueued on lanes[0]'s
         stream, and the traversals of one stage — all samples' primaries, then per bounce all shadow and continuation rays —
-        go out as ONE rtamd_trace_batch_device launch (up to 8 samples: 16 ray lists), so that the slow tail of a list runs
+        go out as ONE rtamd_trace_image_batch_device launch (up to 8 samples: 16 ray lists), so that the slow tail of a list runs
         beside the other lists' rays instead of beside an idle GPU.  Same buffers, bit for bit, as sample() gives each sample.
         This is ONE call into the library (rtamd_multibounce_sample_batch_device, the chain as a C entry point).
         records: a list of dicts (one per sample), filled like sample()'s record — intermediate buffers can only be copied
@@ -181,7 +181,7 @@ class MultiBounce:
             for k, s in enumerate(samples):
                 ox, oy = sample_offset(s)
                 tr.generate_rays_tiles_device(W, H, self.inv, ox, oy, self.rank, self.world, lanes[k].dir.data_ptr())
-            tr.trace_batch_device([(n, ln.cam_org.data_ptr(), ln.dir.data_ptr(), ln.hits.data_ptr()) for ln in lanes])
+            tr.trace_image_batch_device([(n, ln.cam_org.data_ptr(), ln.dir.data_ptr(), ln.hits.data_ptr()) for ln in lanes], W, self.world)
             head.rays += self.n_primary * K
             for k, ln in enumerate(lanes):
                 rec(k, 0, dir=ln.dir, hits=ln.hits)
@@ -205,7 +205,7 @@ class MultiBounce:
                         cont = t["reflect"] if s % 2 == 0 else t["ambient"]
                         jobs.append((n, t["org"].data_ptr(), cont.data_ptr(), ln.hits.data_ptr()))
                         cur[k] = (t["org"], cont)
-                tr.trace_batch_device(jobs)
+                tr.trace_image_batch_device(jobs, W, self.world)
                 head.rays += surfaces
                 for k, ln in enumerate(lanes):
                     t = ln.targets[depth & 1]

@@ -226,6 +226,12 @@ class HipRayTracer:
         arr = (_ffi.TraceJob * len(jobs))(*[_ffi.TraceJob(int(n), o or None, d or None, h or None) for n, o, d, h in jobs])
         self._check(self._lib.rtamd_trace_batch_device(self._h, len(jobs), arr))
 
+    def trace_image_batch_device(self, jobs, width, tile_world=1):
+        """rtamd_trace_image_batch_device: ray lists that are images (scan-line order of `width` pixels per row, or the tile-major
+        shard layout for tile_world > 1), traced in 8x8-pixel work items.  jobs as for trace_batch_device."""
+        arr = (_ffi.TraceJob * len(jobs))(*[_ffi.TraceJob(int(n), o or None, d or None, h or None) for n, o, d, h in jobs])
+        self._check(self._lib.rtamd_trace_image_batch_device(self._h, len(jobs), arr, int(width), int(tile_world)))
+
     # ---- ray generation / assembly -----------------------------------------
     def generate_rays(self, width, height, inv_proj_view):
         inv = np.ascontiguousarray(inv_proj_view, dtype=np.float32).reshape(16)

@@ -831,3 +831,54 @@ def test_trace_batch_equals_list_by_list(tracer, dyn_thresh):
     finally:
         tracer.set_kernel_variant(0)
         tracer.set_option("dyn_thresh", 0)
+
+
+@pytest.mark.parametrize("dyn_thresh", [0, 32])
+def test_trace_image_batch_equals_plain_lists(tracer, dyn_thresh):
+    """rtamd_trace_image_batch_device: ray lists that are images -- scan-line order with widths that are no multiple of 8, one
+    row, one column, a single list, an empty one; and the tile-major shard layout -- are traced in 8x8-pixel work items and give,
+    list by list, the bits of rtamd_trace_device in the same places; entries the items touch beyond a list's end stay untouched."""
+    import torch
+    g = load_golden("bunny")
+    tracer.upload_scene(g["scene"])
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(23)
+    lo, hi = g["scene"]["positions"].min(0), g["scene"]["positions"].max(0)
+
+    def make(n):
+        org = ((lo + hi) / 2 + rng.uniform(-1.0, 1.0, (n, 3)) * (hi - lo)).astype(np.float32)
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        d[::11] = 0.0                                                    # NO_RAY
+        t_org, t_dir = torch.from_numpy(org).to(dev), torch.from_numpy(d).to(dev)
+        # 64 guard entries behind the list: an item that ran past the end would write there
+        return t_org, t_dir, torch.full((n + 64, 4), -3.0, dtype=torch.float32, device=dev), torch.full((max(n, 1), 4), -5.0, dtype=torch.float32, device=dev)
+
+    tracer.set_option("dyn_thresh", dyn_thresh)
+    try:
+        cases = [("scan-line", 70, [70 * 37, 70 * 1, 0, 70 * 8, 70 * 9]), ("scan-line", 1, [1 * 130]), ("scan-line", 8, [8 * 8]),
+                 ("scan-line", 640, [640 * 33]), ("tiles", 0, [3 * 1024, 1024, 0, 5 * 1024]), ("tiles", 0, [2 * 1024])]
+        for variant in (0, 1):
+            tracer.set_kernel_variant(variant)
+            for kind, width, lengths in cases:
+                bufs = [make(n) for n in lengths]
+                jobs = [(n, b[0].data_ptr() if n else 0, b[1].data_ptr() if n else 0, b[2].data_ptr() if n else 0) for n, b in zip(lengths, bufs)]
+                torch.cuda.synchronize()
+                tracer.trace_image_batch_device(jobs, width, tile_world=3 if kind == "tiles" else 1)
+                for n, b in zip(lengths, bufs):
+                    if n:
+                        tracer.trace_device(n, b[0].data_ptr(), b[1].data_ptr(), b[3].data_ptr())
+                tracer.synchronize()
+                for n, b in zip(lengths, bufs):
+                    assert bool((b[2][n:] == -3.0).all()), (variant, kind, width, n)
+                    if n:
+                        assert torch.equal(b[2][:n].view(torch.int32), b[3].view(torch.int32)), (variant, kind, width, n)
+        g0 = make(70 * 3)
+        with pytest.raises(RtamdError):
+            tracer.trace_image_batch_device([(70 * 3 - 1, g0[0].data_ptr(), g0[1].data_ptr(), g0[2].data_ptr())], 70)      # not whole rows
+        with pytest.raises(RtamdError):
+            tracer.trace_image_batch_device([(70 * 3, g0[0].data_ptr(), g0[1].data_ptr(), g0[2].data_ptr())], 0)          # no width
+        with pytest.raises(RtamdError):
+            tracer.trace_image_batch_device([(70 * 3, g0[0].data_ptr(), g0[1].data_ptr(), g0[2].data_ptr())], 0, tile_world=2)   # not whole tiles
+    finally:
+        tracer.set_kernel_variant(0)
+        tracer.set_option("dyn_thresh", 0)

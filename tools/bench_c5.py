@@ -79,8 +79,11 @@ torch.cuda.synchronize()
 if world > 1:
     dist.barrier()
     torch.cuda.synchronize()
+import gc
+gc.collect(); gc.disable()      # a cyclic collection inside the timed region is a 40 ms host stall in one sample_batch call (seen at random calls: 10 % of a 64-spp run)
 t0 = time.perf_counter()
 run(args.spp)
+t_enqueued = time.perf_counter() - t0
 torch.cuda.synchronize()
 if world > 1:
     dist.barrier()
@@ -104,4 +107,4 @@ print(json.dumps({"metric": "Mrays/s", "value": round(rays / dt / 1e6, 1), "unit
                              "rays_per_pixel_sample": round(rays / (n * args.spp), 3), "samples_in_flight": len(mb.lanes), "samples_per_trace_launch": args.batch or 1,
                              "chain": "rtamd_multibounce_sample_batch_device (C entry point)" if args.batch else "issued call by call from raytracer_amd/multibounce.py",
                              "parallelism": f"tiles{world}" if world > 1 else (f"rank 0's share of tiles{args.share_of}, alone on one GPU" if args.share_of > 1 else "single")},
-                  "seconds": round(dt, 4), "ms_per_sample_frame": round(dt / args.spp * 1e3, 3), "data": "synthetic", "dtype": "f32"}))
+                  "seconds": round(dt, 4), "host_enqueue_seconds": round(t_enqueued, 4), "ms_per_sample_frame": round(dt / args.spp * 1e3, 3), "data": "synthetic", "dtype": "f32"}))
