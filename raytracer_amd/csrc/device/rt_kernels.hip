@@ -744,7 +744,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
     // list by list: it starts a list without re-fill and switches re-fill on for the rest of that list as soon as its own
     // visits in it (at least 32) had under half of the lanes active.
     uint32_t dyn_thresh = p.dyn_thresh, dyn_age = 0;
-    const bool per_list = MODE == MODE_TRACE && p.dyn_auto && p.n_frames > 1u;
+    const bool per_list = MODE == MODE_TRACE && p.dyn_auto && (p.n_frames > 1u || p.width != 0u || p.tiles_x != 0u);
     uint32_t probe_job = 0xFFFFFFFFu, probe_inner = 0, probe_lanes = 0;
     if (per_list) dyn_thresh = 1u;
     else if (p.dyn_auto && p.stats_prev) {

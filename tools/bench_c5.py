@@ -25,10 +25,11 @@ ap.add_argument("--height", type=int, default=2160)
 ap.add_argument("--depth", type=int, default=3)
 ap.add_argument("--gpus", type=int, default=1)
 ap.add_argument("--batch", type=int, default=-1, help="samples in lock step per call of the chain's C entry point (rtamd_multibounce_sample_batch_device, "
-                                                      "1..8: every stage's traversals of those samples are ONE rtamd_trace_batch_device launch); 0: the chain issued "
-                                                      "from Python, one sample per lane, a launch per traversal (MultiBounce.sample); -1 = auto: 8 (for the whole frame "
-                                                      "on one GPU both measure the same, 6.95 vs 7.02 Grays/s; a 1/8 tile share: 1.10 -> 0.87 ms per sample frame)")
-ap.add_argument("--groups", type=int, default=2, help="with --batch: batches in flight (streams)")
+                                                      "1..8: every stage's traversals of those samples are ONE rtamd_trace_image_batch_device launch); 0: the chain issued "
+                                                      "from Python, one sample per lane, a launch per traversal (MultiBounce.sample); -1 = auto: 1 for the whole frame on one GPU "
+                                                      "(round 3, lists traced as images with the waves' own re-fill choice: 1 / 2 / 4 / 8 samples per call on 4 / 2 / 2 / 2 streams "
+                                                      "measure 8.17 / 7.85 / 7.69 / 7.59 Grays/s), 8 for a tile share (1/8 share: 1.10 -> 0.87 ms per sample frame)")
+ap.add_argument("--groups", type=int, default=0, help="with --batch: batches in flight (streams); 0 = auto: 4 with one sample per call (one per default hardware queue), else 2")
 ap.add_argument("--share-of", type=int, default=0, help="one process, one GPU: trace only rank 0's tile share of a split over that many ranks "
                                                          "(what one rank of an N-GPU run has to do; for scaling expectations)")
 ap.add_argument("--lanes", type=int, default=4, help="samples in flight (streams); measured 1 / 2 / 3 / 4 / 6: 6.21 / 6.71 / 6.44 / 6.92 / 6.22 Grays/s (4 = one per default hardware queue)")
@@ -49,7 +50,9 @@ if args.share_of > 1 and world == 1:
 else:
     world_for_tiles, rank_for_tiles = world, rank
 if args.batch < 0:
-    args.batch = 8
+    args.batch = 1 if world_for_tiles == 1 else 8
+if args.groups <= 0:
+    args.groups = 4 if args.batch == 1 else 2
 model, camera, _, _, tex = bench.build_workload("atrium_1080p")
 camera.aspect = W / H
 sc = model.scene_arrays()
