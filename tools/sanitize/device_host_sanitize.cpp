@@ -131,6 +131,14 @@ int main() {
         CHECK(rtamd_trace_batch_device(ctx, 17, jobs) == RTAMD_ERR_INVALID_ARGUMENT);
         CHECK(rtamd_trace_batch_device(ctx, 0, jobs) == RTAMD_ERR_INVALID_ARGUMENT);
         jobs[1].n = ne + 1; CHECK(rtamd_trace_batch_device(ctx, 2, jobs) == RTAMD_ERR_INVALID_ARGUMENT); jobs[1].n = ne - 7;   // past the end of org / dir
+        // round 3: the same lists as images (8x8-pixel work items): tile-major shard layout, scan-line order, ragged and bad sizes
+        for (int k = 0; k < 16; k++) jobs[k].n = k % 3 == 2 ? 0u : (uint64_t)(ne - 1024 * (k % 2));
+        for (uint32_t nj : {1u, 3u, 16u}) CHECK(rtamd_trace_image_batch_device(ctx, nj, jobs, 0, 3) == RTAMD_OK);
+        jobs[0].n = ne - 7; CHECK(rtamd_trace_image_batch_device(ctx, 1, jobs, 0, 3) == RTAMD_ERR_INVALID_ARGUMENT);     // not whole tiles
+        for (uint32_t wd : {1u, 8u, 37u, 64u}) { jobs[0].n = (ne / wd) * wd; jobs[1].n = wd; CHECK(rtamd_trace_image_batch_device(ctx, 2, jobs, wd, 1) == RTAMD_OK); }
+        jobs[0].n = 37 * 5 + 1; CHECK(rtamd_trace_image_batch_device(ctx, 1, jobs, 37, 1) == RTAMD_ERR_INVALID_ARGUMENT);    // not whole rows
+        jobs[0].n = 37 * 5; CHECK(rtamd_trace_image_batch_device(ctx, 1, jobs, 0, 1) == RTAMD_ERR_INVALID_ARGUMENT);         // no width
+        jobs[0].n = ne + 1024; CHECK(rtamd_trace_image_batch_device(ctx, 1, jobs, 0, 3) == RTAMD_ERR_INVALID_ARGUMENT);      // past the end of org / dir
         CHECK(rtamd_surface_from_hits_device(ctx, ne, d_org, d_dir, d_hits, 1, d_pos, d_nm) == RTAMD_OK);
         rtamd_dispatch_desc dd{}; dd.width = W; dd.height = H; dd.position = d_pos; dd.normal_mat = d_nm; dd.light_pos[1] = 10.f; dd.camera_pos[2] = 45.f;
         dd.noise_offset_scale[2] = 1.f; dd.noise_offset_scale[3] = 1.f; dd.tile_rank = 2; dd.tile_world = 3;
@@ -140,6 +148,49 @@ int main() {
         dd.tile_rank = 0; dd.tile_world = 0; CHECK(rtamd_dispatch_rays_device(ctx, &dd, &dout) == RTAMD_ERR_INVALID_ARGUMENT);     // whole frame > the shard buffers
         CHECK(hipDeviceSynchronize() == hipSuccess);
         for (float *q : {d_dir, d_org, d_hits, d_pos, d_nm, d_out}) (void)hipFree(q);
+    }
+    // round 3: config 5's chain as one call (two samples, a tile shard and the whole frame), and the device list (one GPU named twice, copy transport)
+    for (uint32_t world : {1u, 3u}) {
+        rtamd_multibounce_desc md{}; md.width = W; md.height = H; std::memcpy(md.inv_proj_view, ipv, sizeof ipv); md.near_plane = 0.01f; md.far_plane = 1000.f;
+        md.cam_pos[2] = 45.f; md.light_pos[1] = 10.f; md.has_normals = 1; md.max_depth = 3; md.noise_size = 5; md.tile_rank = world - 1; md.tile_world = world;
+        const uint64_t ne = rtamd_multibounce_entries(&md);
+        CHECK(ne > 0 && rtamd_multibounce_primary_rays(&md) <= ne);
+        float *pool = nullptr; CHECK(hipMalloc(&pool, 2 * 14 * ne * 16 + 16) == hipSuccess);
+        rtamd_multibounce_lane lanes[2];
+        for (int k = 0; k < 2; k++) {
+            float *q = pool + (size_t)k * 14 * ne * 4; auto take = [&]() { float *r = q; q += ne * 4; return r; };
+            lanes[k].cam_org = take(); lanes[k].dir = take(); lanes[k].hits = take(); lanes[k].position = take(); lanes[k].normal_mat = take();
+            for (int t = 0; t < 2; t++) { lanes[k].org[t] = take(); lanes[k].shadow_dir[t] = take(); lanes[k].reflect_dir[t] = take(); lanes[k].ambient_dir[t] = take(); }
+            lanes[k].shadow_hits = take();
+            CHECK(rtamd_multibounce_prepare_lane_device(ctx, &md, &lanes[k]) == RTAMD_OK);
+        }
+        uint64_t *counter = (uint64_t *)(pool + 2 * 14 * ne * 4); CHECK(hipMemset(counter, 0, 8) == hipSuccess);
+        const uint32_t samples[2] = {4, 7};
+        CHECK(rtamd_multibounce_sample_batch_device(ctx, &md, samples, 2, lanes, counter) == RTAMD_OK);
+        CHECK(rtamd_multibounce_sample_batch_device(ctx, &md, samples, 9, lanes, counter) == RTAMD_ERR_INVALID_ARGUMENT);
+        rtamd_multibounce_lane twice[2] = {lanes[0], lanes[0]};
+        CHECK(rtamd_multibounce_sample_batch_device(ctx, &md, samples, 2, twice, counter) == RTAMD_ERR_INVALID_ARGUMENT);
+        CHECK(hipDeviceSynchronize() == hipSuccess);
+        uint64_t traced = 0; CHECK(hipMemcpy(&traced, counter, 8, hipMemcpyDeviceToHost) == hipSuccess); CHECK(traced >= 2 * rtamd_multibounce_primary_rays(&md));
+        (void)hipFree(pool);
+    }
+    {
+        const int devs[3] = {0, 0, 0};
+        rtamd_multi *m = nullptr;
+        CHECK(rtamd_multi_create(devs, 3, 0, &m) == RTAMD_ERR_INVALID_ARGUMENT && m == nullptr);       // RCCL: one rank per GPU
+        CHECK(rtamd_multi_create(devs, 3, RTAMD_MULTI_TRANSPORT_COPY, &m) == RTAMD_OK && m);
+        if (m) {
+            CHECK(rtamd_multi_upload_scene(m, &sc) == RTAMD_OK);
+            for (uint32_t s = 0; s < 2; s++) CHECK(rtamd_multi_upload_texture(m, s, tex.data(), 7, 5) == RTAMD_OK);
+            rtamd_frame_desc fd[3]; for (auto &f : fd) f = d;
+            std::vector<uint32_t> px(3 * n); std::vector<float> pf(3 * n * 4);
+            for (int rep = 0; rep < 3; rep++) CHECK(rtamd_multi_render_batch(m, 3, fd, RTAMD_GATHER_RGBA8, px.data()) == RTAMD_OK);
+            CHECK(rtamd_multi_render_batch(m, 2, fd, RTAMD_GATHER_RGBA32F, pf.data()) == RTAMD_OK);
+            CHECK(rtamd_multi_render_batch(m, 17, fd, RTAMD_GATHER_RGBA8, px.data()) == RTAMD_ERR_INVALID_ARGUMENT);
+            float g_ms = 0, a_ms = 0; CHECK(rtamd_multi_last_gather_ms(m, &g_ms, &a_ms) == RTAMD_OK);
+            CHECK(rtamd_multi_synchronize(m) == RTAMD_OK);
+            rtamd_multi_destroy(m);
+        }
     }
     CHECK(rtamd_abi_version() == RTAMD_ABI_VERSION);
     CHECK(rtamd_set_option(ctx, "no_such", 1) != RTAMD_OK);
