@@ -499,7 +499,9 @@ int rtamd_last_kernel_ms(rtamd_context *ctx, float *ms);
 /* What the last render / trace launch on the current stream measured about its rays (sampled over 1/8 of the
  * waves; blocks until that launch is done; any output may be NULL): the share of node visits in which every
  * active lane of a wave visited the same node, the share of lanes active per visit, and the lane re-fill
- * threshold the launch ran with.  These are the signals "dyn_thresh" = auto steers by. */
+ * threshold the launch ran with.  These are the signals "dyn_thresh" = auto steers by from one launch to the next (fused
+ * shader, plain ray lists).  Launches of image lists and of several lists report 1: there every wave chooses for itself, list by
+ * list, from its own first visits in the list. */
 int rtamd_last_launch_coherence(rtamd_context *ctx, float *uniform_fraction, float *lane_utilisation, uint32_t *dyn_thresh_used);
 
 /* Kernel variant used by render/trace: 0 = default (persistent wave64 queue),
@@ -514,6 +516,8 @@ int rtamd_set_kernel_variant(rtamd_context *ctx, int variant);
  *                       measured and keeps 1 while at least 50 % of the lanes are active per node visit
  *                       (camera rays, sun shadow rays), switches to 32 below that (triangle soups, bounces)
  *                       for 64 launches, then probes one launch at 1 again; the first launch uses 1;
+ *                       launches of image lists or of several ray lists (rtamd_trace_[image_]batch_device): every wave chooses
+ *                       per list instead -- no re-fill until its own first 32 visits in a list had under half of the lanes active;
  *  "leaf_thresh" 1..64  lanes waiting at a leaf are served once this many wait (64 = classic
  *                       while-while traversal, 1 = if-if), or once half of the wave's busy lanes wait, whichever is fewer (a wave
  *                       with few rays left does not make a lane at a leaf wait for a count the others can hardly reach).
