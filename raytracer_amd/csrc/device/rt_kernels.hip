@@ -1243,6 +1243,22 @@ __global__ void k_assemble_tiles(const uint32_t *__restrict__ gathered, uint32_t
     for (uint32_t e = 0; e < elems; e++) out[dst * elems + e] = gathered[src * elems + e];
 }
 
+// The same for one-word pixels (RGBA8) of frames whose width is a multiple of 4: a thread moves four neighbouring pixels of a
+// tile row (tiles are 32 wide, so the four share their tile) with one 16-byte load and one 16-byte store.  The one-pixel form
+// moves 4 bytes per lane and sits at 3.5 TB/s; this one at the rate of the RGBA32F copy.
+__global__ void k_assemble_tiles_px4(const uint32_t *__restrict__ gathered, uint32_t width, uint32_t height, uint32_t world,
+                                     uint32_t tiles_x, uint32_t tiles_per_rank, uint32_t *__restrict__ out) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;       // group of four pixels of the frame, scan-line order
+    if (q >= (width >> 2) * height) return;
+    const uint32_t f = blockIdx.y, n_frames = gridDim.y;
+    const uint32_t x = (q % (width >> 2)) << 2, y = q / (width >> 2);
+    const uint32_t g = (y >> 5) * tiles_x + (x >> 5);
+    const uint32_t r = g % world, j = g / world;
+    const size_t src = (((size_t)r * n_frames + f) * tiles_per_rank + j) * RTAMD_TILE_PIXELS + ((y & 31u) * 32u + (x & 31u));
+    const size_t dst = (size_t)f * width * height + (size_t)y * width + x;
+    *reinterpret_cast<uint4 *>(out + dst) = *reinterpret_cast<const uint4 *>(gathered + src);
+}
+
 // util/display.frag:9 writes the float colour target to the window's 8-bit back buffer; the conversion is the
 // GL one (4.6 spec 2.3.5: clamp to [0,1], x255, round to nearest; NaN -> 0 here).  HBM stream: 16 B in, 4 B out.
 __device__ __forceinline__ uint32_t to_unorm8(float x) {

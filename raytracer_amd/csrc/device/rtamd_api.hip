@@ -1292,8 +1292,12 @@ int rtamd_assemble_tile_batch_device(rtamd_context *ctx, const void *gathered, u
     uint32_t n = width * height;
     if ((rc = check_range(ctx, gathered, (uint64_t)tile_world * n_frames * per_rank * RTAMD_TILE_PIXELS * elems_per_pixel * 4, "gathered")) ||
         (rc = check_range(ctx, frames_out, (uint64_t)n_frames * n * elems_per_pixel * 4, "frames_out"))) return rc;
-    hipLaunchKernelGGL(k_assemble_tiles, dim3((n + 255) / 256, n_frames), dim3(256), 0, ctx->stream, (const uint32_t *)gathered, width, height,
-                       tile_world, tiles_x, per_rank, elems_per_pixel, (uint32_t *)frames_out);
+    if (elems_per_pixel == 1 && width % 4 == 0 && (((uintptr_t)gathered | (uintptr_t)frames_out) & 15u) == 0)      // RGBA8, the gather's usual format: four pixels per thread
+        hipLaunchKernelGGL(k_assemble_tiles_px4, dim3((n / 4 + 255) / 256, n_frames), dim3(256), 0, ctx->stream, (const uint32_t *)gathered, width, height,
+                           tile_world, tiles_x, per_rank, (uint32_t *)frames_out);
+    else
+        hipLaunchKernelGGL(k_assemble_tiles, dim3((n + 255) / 256, n_frames), dim3(256), 0, ctx->stream, (const uint32_t *)gathered, width, height,
+                           tile_world, tiles_x, per_rank, elems_per_pixel, (uint32_t *)frames_out);
     HIP_TRY(ctx, hipGetLastError());
     return RTAMD_OK;
 }
