@@ -518,6 +518,8 @@ int rtamd_set_kernel_variant(rtamd_context *ctx, int variant);
  *                       for 64 launches, then probes one launch at 1 again; the first launch uses 1;
  *                       launches of image lists or of several ray lists (rtamd_trace_[image_]batch_device): every wave chooses
  *                       per list instead -- no re-fill until its own first 32 visits in a list had under half of the lanes active;
+ *  "dyn_incoherent" 2..64  the threshold "dyn_thresh" = auto switches to for incoherent rays (default 32: measured flat over
+ *                       24..32 on config 4 and on config 5's lists, 3-8 % slower at 16 and at 48, profiles/r03_ab_dyn_incoherent.txt);
  *  "leaf_thresh" 1..64  lanes waiting at a leaf are served once this many wait (64 = classic
  *                       while-while traversal, 1 = if-if), or once half of the wave's busy lanes wait, whichever is fewer (a wave
  *                       with few rays left does not make a lane at a leaf wait for a count the others can hardly reach).

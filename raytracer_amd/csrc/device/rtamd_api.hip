@@ -523,6 +523,9 @@ int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value) {
         if (value == 0) { ctx->dyn_auto = true; ctx->dyn_thresh_fused = 1; ctx->dyn_thresh_trace = 1; }
         else { ctx->dyn_auto = false; ctx->dyn_thresh_fused = ctx->dyn_thresh_trace = (uint32_t)value; }
         for (auto &sl : ctx->slots) sl.launches = 0;
+    } else if (!std::strcmp(name, "dyn_incoherent")) {
+        if (value < 2 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "dyn_incoherent must be 2..64");
+        ctx->dyn_incoherent = (uint32_t)value;
     } else if (!std::strcmp(name, "leaf_thresh")) {
         if (value < 1 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "leaf_thresh must be 1..64");
         ctx->leaf_thresh = (uint32_t)value;

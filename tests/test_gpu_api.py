@@ -854,6 +854,7 @@ def test_trace_image_batch_equals_plain_lists(tracer, dyn_thresh):
         return t_org, t_dir, torch.full((n + 64, 4), -3.0, dtype=torch.float32, device=dev), torch.full((max(n, 1), 4), -5.0, dtype=torch.float32, device=dev)
 
     tracer.set_option("dyn_thresh", dyn_thresh)
+    tracer.set_option("dyn_incoherent", 48 if dyn_thresh == 0 else 32)    # what auto switches to for these random rays
     try:
         cases = [("scan-line", 70, [70 * 37, 70 * 1, 0, 70 * 8, 70 * 9]), ("scan-line", 1, [1 * 130]), ("scan-line", 8, [8 * 8]),
                  ("scan-line", 640, [640 * 33]), ("tiles", 0, [3 * 1024, 1024, 0, 5 * 1024]), ("tiles", 0, [2 * 1024])]
@@ -882,3 +883,6 @@ def test_trace_image_batch_equals_plain_lists(tracer, dyn_thresh):
     finally:
         tracer.set_kernel_variant(0)
         tracer.set_option("dyn_thresh", 0)
+        tracer.set_option("dyn_incoherent", 32)
+    with pytest.raises(RtamdError):
+        tracer.set_option("dyn_incoherent", 1)

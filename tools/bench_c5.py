@@ -32,6 +32,7 @@ ap.add_argument("--batch", type=int, default=-1, help="samples in lock step per 
 ap.add_argument("--groups", type=int, default=0, help="with --batch: batches in flight (streams); 0 = auto: 4 with one sample per call (one per default hardware queue), else 2")
 ap.add_argument("--share-of", type=int, default=0, help="one process, one GPU: trace only rank 0's tile share of a split over that many ranks "
                                                          "(what one rank of an N-GPU run has to do; for scaling expectations)")
+ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="rtamd_set_option before anything is launched (A/B runs)")
 ap.add_argument("--lanes", type=int, default=4, help="samples in flight (streams); measured 1 / 2 / 3 / 4 / 6: 6.21 / 6.71 / 6.44 / 6.92 / 6.22 Grays/s (4 = one per default hardware queue)")
 args = ap.parse_args()
 W, H, n = args.width, args.height, args.width * args.height
@@ -57,6 +58,8 @@ model, camera, _, _, tex = bench.build_workload("atrium_1080p")
 camera.aspect = W / H
 sc = model.scene_arrays()
 tr = HipRayTracer(local_rank)
+for kv in args.option:
+    tr.set_option(kv.partition('=')[0], int(kv.partition('=')[2]))
 tr.upload_scene(sc)
 rng = np.random.default_rng(3)
 v = rng.normal(size=(512, 512, 3)); v /= np.linalg.norm(v, axis=-1, keepdims=True)
