@@ -34,16 +34,23 @@ tr.set_stream(st.cuda_stream)
 
 
 def timed(fn, reps=100):
-    for _ in range(5):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(st)
-    for _ in range(reps):
-        fn()
-    e1.record(st)
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    """Mean of `reps` back-to-back calls; the better of three such rounds.  (One round is not enough right after large
+    allocations: the first kernel timed after ~1 GB of fresh buffers measured 0.41-0.56 ms per call instead of 0.027 --
+    the driver was still clearing the new memory -- which is how a 4K k_generate_rays once came out at 0.03 of the HBM peak.)"""
+    best = None
+    for _ in range(3):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            fn()
+        e1.record(st)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        best = ms if best is None else min(best, ms)
+    return best
 
 
 def report(kernel, w, h, ms, bytes_per_px, note=""):
