@@ -690,8 +690,13 @@ __device__ __forceinline__ uint32_t ray_pos_flag(const Ray &r, uint32_t octant_o
 // ---------------------------------------------------------------------------
 // k_persistent — production kernel
 // ---------------------------------------------------------------------------
-template <int MODE, bool COUNT, bool MAT = false, bool F8 = false>
+// SINGLE (fused mode only): the launch is known to hold one frame, and the kernel carries none of the batch's frame look-ups.  Batches (and
+// trace mode) use SINGLE = false, which tests JobParams::n_frames at run time and serves both.  Measured (profiles/r03_ab_batch_template.txt): the
+// single-frame instantiation renders a frame alone 0.8 % (atrium) to 4 % (bunny) faster; a batch-only instantiation is smaller (59 VGPRs, 42
+// instead of 56 spilled SGPRs) and 1.4 % SLOWER on the atrium's batches, so batches keep the kernel that serves both.
+template <int MODE, bool COUNT, bool MAT = false, bool F8 = false, bool SINGLE = false>
 __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(const SceneDev s, const JobParams p) {
+#define IS_BATCH (!SINGLE && p.n_frames > 1u)
     __shared__ uint32_t lds_stack[LDS_STACK_ENTRIES * BLOCK];
     // fused shader: the in-shadow colour of a lane's pixel waits here ([channel][thread]) while its shadow ray is traced
     __shared__ float lds_shadow_col[MODE == MODE_FUSED ? 3 * BLOCK : 1];
@@ -703,7 +708,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
             if (tid == f) lds_frame_out[f][0] = (uint64_t)(uintptr_t)p.frames[f].rgba;     // the job's hit records
         __syncthreads();
     }
-    if (MODE == MODE_FUSED && p.n_frames > 1u) {
+    if (MODE == MODE_FUSED && IS_BATCH) {
         for (uint32_t f = 0; f < p.n_frames; f++)      // f is wave-uniform: scalar loads of the arguments, one lane stores
             if (tid == f) {
                 lds_frame_out[f][0] = (uint64_t)(uintptr_t)p.frames[f].rgba;  lds_frame_out[f][1] = (uint64_t)(uintptr_t)p.frames[f].hit_id;
@@ -803,7 +808,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                     // batch: item -> (frame, item of that frame); everything here is wave-uniform
                     uint32_t frame = 0, item_in_frame = pool_item;
                     const float *f_dir = p.dir, *f_org = p.org;
-                    if (p.n_frames > 1u) {
+                    if (IS_BATCH) {
                         for (uint32_t k = 1; k < p.n_frames; k++) if (pool_item >= k * p.items_per_frame) frame = k;
                         item_in_frame = pool_item - frame * p.items_per_frame;
                         f_dir = p.frames[frame].dir; f_org = p.frames[frame].org;
@@ -814,7 +819,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
                         if (f_dir) {
                             const float *d = f_dir + 3 * (size_t)pr.ray_index, *o = f_org + 3 * (size_t)pr.ray_index;
                             dx = d[0]; dy = d[1]; dz = d[2]; ox = o[0]; oy = o[1]; oz = o[2];
-                        } else if (p.n_frames > 1u) {
+                        } else if (IS_BATCH) {
                             const FrameIO &fr = p.frames[frame];
                             gen_primary_dir(fr.ipv, fr.near_, fr.far_, p.width, p.height, pr.px, pr.py, dx, dy, dz);
                             ox = fr.cam[0]; oy = fr.cam[1]; oz = fr.cam[2];
@@ -969,7 +974,7 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
               float *o_rgba = p.rgba, *o_t = p.hit_t;
               uint32_t *o_id = p.hit_id, *o_cnt = p.counts;
               uint32_t out_i = out_index;
-              if (p.n_frames > 1u) {
+              if (IS_BATCH) {
                   const uint32_t f = out_index >> BATCH_FRAME_SHIFT;
                   out_i = out_index & ((1u << BATCH_FRAME_SHIFT) - 1u);
                   o_rgba = (float *)(uintptr_t)lds_frame_out[f][0]; o_id = (uint32_t *)(uintptr_t)lds_frame_out[f][1];
@@ -1027,6 +1032,8 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
     }
 #endif
 }
+
+#undef IS_BATCH
 
 // ---------------------------------------------------------------------------
 // k_static — A/B baseline: one lane per pixel / ray, one 64-lane item per wave,

@@ -200,7 +200,9 @@ int acquire_slot(rtamd_context *ctx, rtamd_context::Slot **out) {
 
 // The fused persistent kernel's instantiation for (per-pixel counters, material table, 8-bit texture filter).
 void launch_persistent_fused(bool count, bool mat, bool f8, uint32_t grid, hipStream_t st, const SceneDev &s, const JobParams &p) {
-#define RTAMD_FUSED(C, M, F) hipLaunchKernelGGL((k_persistent<MODE_FUSED, C, M, F>), dim3(grid), dim3(BLOCK), 0, st, s, p)
+// (one frame: the instantiation without the batch's frame look-ups; several: the one that serves both, see k_persistent)
+#define RTAMD_FUSED(C, M, F) do { if (p.n_frames > 1u) hipLaunchKernelGGL((k_persistent<MODE_FUSED, C, M, F, false>), dim3(grid), dim3(BLOCK), 0, st, s, p); \
+                                  else hipLaunchKernelGGL((k_persistent<MODE_FUSED, C, M, F, true>), dim3(grid), dim3(BLOCK), 0, st, s, p); } while (0)
     switch ((count ? 4 : 0) | (mat ? 2 : 0) | (f8 ? 1 : 0)) {
         case 0: RTAMD_FUSED(false, false, false); break;
         case 1: RTAMD_FUSED(false, false, true); break;

@@ -20,7 +20,9 @@ def meta():
 
 def test_production_kernels_keep_no_scratch_and_spill_no_vgpr(meta):
     # the fused shader (default: no per-pixel counters, no material table, float texture filter) and ray_trace
-    for name in ("rtamd::k_persistent<0, false, false, false>", "rtamd::k_persistent<1, false, false, false>"):
+    # (last argument of the fused kernel: the single-frame instantiation / the one batches use, which serves both)
+    for name in ("rtamd::k_persistent<0, false, false, false, false>", "rtamd::k_persistent<0, false, false, false, true>",
+                 "rtamd::k_persistent<1, false, false, false, false>"):
         m = meta[name]
         assert m["private_segment_fixed_size"] == 0, (name, m)
         assert m["vgpr_spill_count"] == 0, (name, m)
@@ -29,7 +31,7 @@ def test_production_kernels_keep_no_scratch_and_spill_no_vgpr(meta):
 def test_persistent_kernels_fit_eight_workgroups_per_cu(meta):
     """8 waves per SIMD: at most 64 VGPRs, and eight 256-thread workgroups' LDS inside a CU's 160 KiB."""
     pers = {k: v for k, v in meta.items() if k.startswith("rtamd::k_persistent<")}
-    assert len(pers) == 10            # fused: counters x materials x filter; trace: counters
+    assert len(pers) == 18            # fused: counters x materials x filter x (single frame | batch); trace: counters
     for name, m in pers.items():
         assert m["vgpr_count"] <= 64, (name, m)
         assert 8 * m["group_segment_fixed_size"] <= 160 * 1024, (name, m)

@@ -9,7 +9,8 @@ vals, cur, busy = {}, None, {}
 for line in open(summary):
     m = re.match(r"\[(pmc_\w+)\] (.*)", line)
     if m:
-        cur = m.group(1) if "k_persistent<0, false" in m.group(2) else None    # the dominant kernel: fused, no test counters
+        # the dominant kernel: fused, no test counters, the instantiation batches use (last template argument false)
+        cur = m.group(1) if re.search(r"k_persistent<0, false, (true|false), (true|false), false>", m.group(2)) else None
         continue
     m = re.match(r"\s+(\w+)\s+([\d.]+)\s+\(n=(\d+)\)", line)
     if m and cur:
