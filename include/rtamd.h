@@ -528,8 +528,9 @@ int rtamd_set_kernel_variant(rtamd_context *ctx, int variant);
  *  "queue_stride" 1..4096  u32 words between the counters (default 64 = 256 B, one memory
  *                       channel each);
  *  "max_blocks_per_cu" 0..64  cap on the persistent grid, in workgroups per CU.  0 (default) = automatic: all that
- *                       fit (8) for a launch on its own, 16 / n when n launches of this context are in flight on
- *                       different streams, so that the grids of overlapping frames are resident side by side;
+ *                       fit (8) for a launch on its own (7 for a fused launch of ONE frame: it is bounded by its slowest
+ *                       pixels, and fewer waves per SIMD run each faster), 16 / n when n launches of this context are in
+ *                       flight on different streams, so that the grids of overlapping frames are resident side by side;
  *  "queue_block" 1..65536  consecutive schedule positions (work items) a queue owns per turn, i.e. the size of
  *                       the screen region the waves of one XCD share (default 256 for frames, 1 for ray lists);
  *  "validate_buffers" 0/1  (default 1) every "_device" entry point checks, with hipMemGetAddressRange, that each buffer it is

@@ -276,6 +276,11 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
             (void)hipGetLastError();   // hipErrorNotReady is an answer, not a failure
             const int share = (16 * 256 / BLOCK) / inflight;   // 16 workgroups of 256 threads per CU, in units of this build's workgroup
             if (share < per_cu) per_cu = share < 1 ? 1 : share;
+            // One frame in one launch with nothing beside it is bounded by its slowest items, not by throughput: 7 waves per SIMD instead of
+            // 8 run each of them faster (a frame alone: bunny -5.5 %, 1 M soup -5.6 %, atrium +0.5 %, f16 equal; profiles/r03_ab_blocks_per_cu.txt).
+            // Batches and frames pipelined over streams keep all that fit.
+            const int lone = 7 * 256 / BLOCK;
+            if (mode == MODE_FUSED && p.n_frames <= 1u && inflight == 1 && per_cu > lone) per_cu = lone;
         }
         uint32_t grid = (uint32_t)(ctx->num_cu * per_cu);
         uint32_t need = (p.n_items + (BLOCK / 64) - 1) / (BLOCK / 64);
