@@ -520,10 +520,12 @@ int rtamd_set_kernel_variant(rtamd_context *ctx, int variant);
  *                       per list instead -- no re-fill until its own first 32 visits in a list had under half of the lanes active;
  *  "dyn_incoherent" 2..64  the threshold "dyn_thresh" = auto switches to for incoherent rays (default 32: measured flat over
  *                       24..32 on config 4 and on config 5's lists, 3-8 % slower at 16 and at 48, profiles/r03_ab_dyn_incoherent.txt);
- *  "leaf_thresh" 1..64  lanes waiting at a leaf are served once this many wait (64 = classic
+ *  "leaf_thresh" 0..64  lanes waiting at a leaf are served once this many wait (64 = classic
  *                       while-while traversal, 1 = if-if), or once half of the wave's busy lanes wait, whichever is fewer (a wave
  *                       with few rays left does not make a lane at a leaf wait for a count the others can hardly reach).
- *                       Per-lane order is untouched, so no result bit depends on it;
+ *                       Per-lane order is untouched, so no result bit depends on it.  0 (default) = by what the wave is doing:
+ *                       20 while it runs without lane re-fill (coherent rays), 8 while a fused frame re-fills (soups), 12 while
+ *                       a ray list re-fills (bounces); "leaf_thresh_coherent" / "leaf_thresh_refill" 1..64 set the two sides alone;
  *  "num_queues" 1..32   work-queue counters (8 = one per XCD);
  *  "queue_stride" 1..4096  u32 words between the counters (default 64 = 256 B, one memory
  *                       channel each);

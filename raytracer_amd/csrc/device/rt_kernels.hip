@@ -124,7 +124,8 @@ struct JobParams {
     uint32_t *queues;             // n_queues counters, 16 dwords apart
     uint32_t n_queues;
     uint32_t dyn_thresh;
-    uint32_t leaf_thresh;
+    uint32_t leaf_thresh;         // lanes waiting at a leaf that release the leaf phase, while the wave runs without lane re-fill (coherent rays) ...
+    uint32_t leaf_thresh_refill;  // ... and while it re-fills (incoherent rays)
     uint32_t shadow_anyhit;       // fused mode: shadow rays stop at the first leaf that leaves t < T_HIT_LIMIT
     uint32_t tex_filter8;         // 1: filter textures as the pinned reference executor does (8-bit weights and lerps), 0: in float
     uint32_t queue_stride;        // u32 words between queue counters
@@ -905,7 +906,8 @@ __global__ void __launch_bounds__(BLOCK) RTAMD_PERSISTENT_ATTR k_persistent(cons
             // rays; a run-time fraction or shift instead of the constant one 1.4 % slower batches: profiles/r03_ab_leaf_release_rule.txt.)
             uint32_t leaf_eff = (uint32_t)__popcll(m_busy) >> 1;
             leaf_eff = leaf_eff < 1u ? 1u : leaf_eff;
-            leaf_eff = leaf_eff < p.leaf_thresh ? leaf_eff : p.leaf_thresh;
+            const uint32_t leaf_cap = dyn_thresh == 1u ? p.leaf_thresh : p.leaf_thresh_refill;
+            leaf_eff = leaf_eff < leaf_cap ? leaf_eff : leaf_cap;
             const uint32_t oct0 = m_busy ? __builtin_amdgcn_readlane(my_oct, (int)__builtin_ctzll(m_busy)) : 0u;
             const bool oct_wave = (oct0 & 8u) && __builtin_amdgcn_ballot_w64(tr.cur != REF_NONE && my_oct != oct0) == 0ull;
             auto inner_loop = [&](auto pos_tag) __attribute__((always_inline)) {

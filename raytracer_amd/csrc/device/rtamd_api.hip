@@ -83,7 +83,10 @@ struct rtamd_context {
     uint32_t dyn_thresh_fused = 1, dyn_thresh_trace = 1;   // starting values; with dyn_auto the kernel adapts them per launch
     bool dyn_auto = true;
     uint32_t dyn_incoherent = 32;
-    uint32_t leaf_thresh = 8;
+    // lanes waiting at a leaf that release the leaf phase (capped at half of the busy lanes): while a wave runs without lane re-fill, and
+    // while it re-fills -- fused shader / ray lists.  Round-3 sweep with the half-of-busy rule in place (profiles/r03_ab_leaf_thresh_by_mode.txt):
+    // coherent 8 -> 20: atrium batches +1.5 %, bunny +0.5 %; re-filling ray lists 8 -> 12: config 5 +1.6 %; re-filling soup frames want 8.
+    uint32_t leaf_thresh = 20, leaf_thresh_refill_fused = 8, leaf_thresh_refill_trace = 12;
     bool shadow_anyhit = true;
     bool tex_filter8 = false;   // option "texture_filter_8bit"
     bool validate_buffers = true;     // *_device entry points check that every buffer lies inside one device allocation (check_range)
@@ -229,7 +232,7 @@ int launch_main(rtamd_context *ctx, int mode, bool count, JobParams &p) {
     p.dyn_auto = ctx->dyn_auto ? 1u : 0u;
     p.dyn_incoherent = ctx->dyn_incoherent;
     p.stats_prev = nullptr; p.stats_cur = nullptr;
-    p.leaf_thresh = ctx->leaf_thresh;
+    p.leaf_thresh = ctx->leaf_thresh; p.leaf_thresh_refill = mode == MODE_FUSED ? ctx->leaf_thresh_refill_fused : ctx->leaf_thresh_refill_trace;
     p.shadow_anyhit = ctx->shadow_anyhit ? 1u : 0u;
     p.tex_filter8 = ctx->tex_filter8 ? 1u : 0u;
     p.queue_stride = ctx->queue_stride; p.queue_block = mode == MODE_FUSED ? ctx->queue_block_fused : ctx->queue_block_trace;
@@ -534,8 +537,15 @@ int rtamd_set_option(rtamd_context *ctx, const char *name, int64_t value) {
         if (value < 2 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "dyn_incoherent must be 2..64");
         ctx->dyn_incoherent = (uint32_t)value;
     } else if (!std::strcmp(name, "leaf_thresh")) {
-        if (value < 1 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "leaf_thresh must be 1..64");
+        if (value < 0 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "leaf_thresh must be 0..64");
+        if (value == 0) { ctx->leaf_thresh = 20; ctx->leaf_thresh_refill_fused = 8; ctx->leaf_thresh_refill_trace = 12; }   // the defaults
+        else ctx->leaf_thresh = ctx->leaf_thresh_refill_fused = ctx->leaf_thresh_refill_trace = (uint32_t)value;
+    } else if (!std::strcmp(name, "leaf_thresh_coherent")) {
+        if (value < 1 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "leaf_thresh_coherent must be 1..64");
         ctx->leaf_thresh = (uint32_t)value;
+    } else if (!std::strcmp(name, "leaf_thresh_refill")) {
+        if (value < 1 || value > 64) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "leaf_thresh_refill must be 1..64");
+        ctx->leaf_thresh_refill_fused = ctx->leaf_thresh_refill_trace = (uint32_t)value;
     } else if (!std::strcmp(name, "queue_stride")) {
         if (value < 1 || value > 4096) return fail(ctx, RTAMD_ERR_INVALID_ARGUMENT, "queue_stride must be 1..4096 words");
         ctx->queue_stride = (uint32_t)value;
@@ -984,7 +994,7 @@ int rtamd_render_device_static(rtamd_context *ctx, const rtamd_frame_desc *desc,
     p.queue_block = ctx->queue_block_fused;
     p.dyn_thresh = ctx->dyn_thresh_fused; p.dyn_auto = 0; p.dyn_incoherent = ctx->dyn_incoherent;
     p.stats_prev = nullptr; p.stats_cur = nullptr;   // no coherence feedback: the re-fill threshold is the context's fixed one
-    p.leaf_thresh = ctx->leaf_thresh;
+    p.leaf_thresh = ctx->leaf_thresh; p.leaf_thresh_refill = ctx->leaf_thresh_refill_fused;
     p.shadow_anyhit = ctx->shadow_anyhit ? 1u : 0u;
     p.tex_filter8 = ctx->tex_filter8 ? 1u : 0u;
     p.spill = ptr + STATIC_QUEUE_WORDS;

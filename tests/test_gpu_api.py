@@ -263,7 +263,7 @@ def test_full_size_atrium_properties(tracer, oracle_a, atrium):
     tracer.upload_texture(0, tex[0]); tracer.upload_texture(1, tex[1])
     inv = camera.inv_proj_view()
     ref = None
-    defaults = {"kernel_variant": 0, "dyn_thresh": 0, "leaf_thresh": 8, "num_queues": 8, "queue_stride": 64,
+    defaults = {"kernel_variant": 0, "dyn_thresh": 0, "leaf_thresh": 0, "num_queues": 8, "queue_stride": 64,
                 "max_blocks_per_cu": 0, "shadow_anyhit": 1, "queue_block": 256}
     try:
         tracer.set_option("shadow_anyhit", 0)   # reference-length shadow traversals: counters comparable with the oracle
@@ -274,7 +274,8 @@ def test_full_size_atrium_properties(tracer, oracle_a, atrium):
                      {"kernel_variant": 0, "dyn_thresh": 64, "leaf_thresh": 1, "num_queues": 3, "max_blocks_per_cu": 5, "queue_block": 7},
                      {"kernel_variant": 0, "dyn_thresh": 1, "leaf_thresh": 24},
                      {"kernel_variant": 0, "dyn_thresh": 1, "leaf_thresh": 8, "num_queues": 16, "max_blocks_per_cu": 0},
-                     {"kernel_variant": 0, "dyn_thresh": 0}, {"kernel_variant": 0, "dyn_thresh": 0}):
+                     {"kernel_variant": 0, "dyn_thresh": 32, "leaf_thresh_coherent": 33, "leaf_thresh_refill": 3},
+                     {"kernel_variant": 0, "dyn_thresh": 0, "leaf_thresh": 0}, {"kernel_variant": 0, "dyn_thresh": 0}):
             for k, v in opts.items():
                 tracer.set_option(k, v)
             r = tracer.render(W, H, camera=(inv, camera.position), has_tex_coords=1, has_normals=1, want=("rgba", "hit_id", "hit_t", "counts"))

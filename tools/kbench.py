@@ -63,7 +63,7 @@ def main():
             mode = o.get("mode", "fused")
             tr.set_option("dyn_thresh", int(o.get("dyn_thresh", 0)))
             tr.set_option("num_queues", int(o.get("num_queues", 8)))
-            tr.set_option("leaf_thresh", int(o.get("leaf_thresh", 8)))
+            tr.set_option("leaf_thresh", int(o.get("leaf_thresh", 0)))
             tr.set_option("queue_stride", int(o.get("queue_stride", 64)))
             tr.set_option("max_blocks_per_cu", int(o.get("blocks", 0)))
             tr.set_option("queue_block", int(o.get("queue_block", 256 if o.get("mode", "fused") == "fused" else 1)))
