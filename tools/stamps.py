@@ -3,7 +3,7 @@
 -DRTAMD_EXP_STAMPS build.  RTAMD_DEVICE_LIB must point at that build:
     hipcc <HIP_FLAGS of raytracer_amd/csrc/Makefile> -DRTAMD_EXP_STAMPS -Iinclude -shared \
           -o raytracer_amd/lib/exp_stamps.so raytracer_amd/csrc/device/rtamd_api.hip
-    RTAMD_DEVICE_LIB=$PWD/raytracer_amd/lib/exp_stamps.so python tools/stamps.py [workload]
+    RTAMD_DEVICE_LIB=$PWD/raytracer_amd/lib/exp_stamps.so python tools/stamps.py [workload [leaf_thresh]]
 The per-item records hold 65 536 items (a 1080p frame has 32 400): use it on 1080p workloads."""
 import ctypes, os, sys
 import numpy as np
@@ -20,7 +20,7 @@ n = W * H
 d_dir = torch.empty((n, 3), dtype=torch.float32, device=dev); tr.generate_rays_device(W, H, camera.inv_proj_view(), d_dir.data_ptr()); tr.synchronize()
 d_org = torch.tensor(np.asarray(camera.position, np.float32), device=dev).repeat(n, 1).contiguous()
 d_rgba = torch.zeros((n, 4), dtype=torch.float32, device=dev)
-tr.set_option('leaf_thresh', 8)
+tr.set_option('leaf_thresh', int(sys.argv[2]) if len(sys.argv) > 2 else 0)     # 0 = the defaults (by mode); 8 = round 2 / early round 3
 prev_dur = prev_ok = None
 for th, nq, ad, pr in ((1, 8, 0, 0),):
     tr.set_option("dyn_thresh", th); tr.set_option("num_queues", nq)
