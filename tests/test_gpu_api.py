@@ -237,6 +237,36 @@ def test_tile_shards_assemble_to_the_full_frame(tracer, world):
         assert np.array_equal(bits(outs[f].cpu().numpy()), bits(full["rgba"] * np.float32(f + 1)))
 
 
+@pytest.mark.parametrize("w,h", [(72, 40), (70, 33), (1920, 1080), (4, 1)])
+def test_rgba8_share_assembly_equals_the_host_assembly(tracer, w, h):
+    """One word per pixel (the display format that crosses xGMI): widths that are multiples of 4 take the four-pixels-per-thread kernel,
+    others and buffers that are not 16-byte aligned the one-pixel kernel; both equal the host restatement, single frames and batches."""
+    import torch
+    rng = np.random.default_rng(w * 1000 + h)
+    for world in (1, 2, 3):
+        per_rank = tracer.tiles_per_rank(w, h, world) * 1024
+        n_frames = 3
+        shares = rng.integers(0, 2**32, size=(world, n_frames, per_rank), dtype=np.uint32)
+        expect = [assemble_tiles_host([shares[r, f].reshape(-1, 1) for r in range(world)], w, h, world, 1).reshape(-1) for f in range(n_frames)]
+        for shift in (0, 1):       # 1: source and destination one word off a 16-byte boundary
+            src = torch.zeros((shares.size + 4,), dtype=torch.int32, device="cuda")
+            src[shift:shift + shares.size] = torch.from_numpy(shares.reshape(-1).view(np.int32)).cuda()
+            dst = torch.full((n_frames * w * h + 4,), -1, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            tracer.assemble_tile_batch_device(src.data_ptr() + 4 * shift, w, h, world, 1, n_frames, dst.data_ptr() + 4 * shift)
+            tracer.synchronize()
+            got = dst.cpu().numpy().view(np.uint32)
+            for f in range(n_frames):
+                assert np.array_equal(got[shift + f * w * h: shift + (f + 1) * w * h], expect[f]), (world, shift, f)
+            assert np.all(got[:shift] == 0xFFFFFFFF) and np.all(got[shift + n_frames * w * h:] == 0xFFFFFFFF)      # nothing outside the frames
+        one = torch.from_numpy(np.ascontiguousarray(shares[:, 0]).reshape(-1).view(np.int32)).cuda()
+        out = torch.zeros((w * h,), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        tracer.assemble_tiles_device(one.data_ptr(), w, h, world, 1, out.data_ptr())
+        tracer.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), expect[0]), world
+
+
 def test_on_device_ray_generation_equals_host_and_oracle(tracer, oracle_a):
     cam = host.Camera(16 / 9, fov=math.radians(75), position=(0.5, 1.5, -2.0), direction=(0.2, -0.1, 0.97))
     inv = cam.inv_proj_view()
