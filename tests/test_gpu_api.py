@@ -718,6 +718,17 @@ def test_batch_of_frames_equals_frame_by_frame(tracer):
     finally:
         tracer.set_option("dyn_thresh", 0)
     same(*_batch_vs_single(tracer, w, h, frames[:3], 1, 1, tile_rank=1, tile_world=3, with8=True))
+    # the other instantiations of the fused kernel (one-frame launches and batches are different ones of each): the executor's 8-bit
+    # texture filter, a material table, both
+    try:
+        for f8, table in ((1, None), (0, [((0.3, 0.3, 0.3), (0.9, 0.6, 0.4), (0.2, 0.2, 0.2), 12.0, 1), ((0.5, 0.5, 0.5), (0.8, 0.8, 0.8), (0.4, 0.4, 0.4), 30.0, 0)]), (1, [((0.1, 0.2, 0.3), (0.7, 0.7, 0.2), (0.9, 0.9, 0.9), 5.0, -1)] * 2)):
+            tracer.set_option("texture_filter_8bit", f8)
+            tracer.upload_materials(table)
+            same(*_batch_vs_single(tracer, w, h, frames[:3], 1, 1))
+            same(*_batch_vs_single(tracer, w, h, frames[1:4], 1, 1, counts=False))
+    finally:
+        tracer.set_option("texture_filter_8bit", 0)
+        tracer.upload_materials(None)
     # ragged frames, the full 16 of a batch; frame outputs may be partly absent
     rw, rh = 37, 19
     sub = lambda a, k: t(np.ascontiguousarray(a[5 * k:5 * k + rh, 8 * k:8 * k + rw]))   # noqa: E731  (k <= 15: inside the 160x120 fixture)
