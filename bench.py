@@ -180,7 +180,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="0 persistent (default), 1 static A/B baseline (always one frame per launch)")
     ap.add_argument("--batch", type=int, default=0,
                     help="frames per launch (rtamd_render_batch_device), 1..16; 1 = one frame at a time.  0 = auto: 8 on one GPU "
-                         "(2 when the scene records exceed the 256 MB Infinity Cache); with N > 1 the frames of one gather")
+                         "(4 for runs under 16 steps); with N > 1 the frames of one gather")
     ap.add_argument("--streams", type=int, default=0,
                     help="one GPU: batches alternate over that many streams (0 = auto: 2, so that the tail of one batch runs beside the "
                          "start of the next; 1: launches never overlap)")
@@ -258,10 +258,7 @@ def main():
 
     per_rank_tiles = tracer.tiles_per_rank(W, H, world)
     n_local_out = n_px if world == 1 else per_rank_tiles * TILE_PIXELS
-    info = tracer.scene_info()
-    scene_mb = (info.inner_node_count * 64 + info.triangle_count * 48) / 1e6
-    # Frames per launch.  One GPU: 8 (2 when the scene records exceed the 256 MB Infinity Cache, where more frames in flight
-    # only evict each other's nodes).  N > 1: the frames of one gather (one collective per G frames: the call costs the root's
+    # Frames per launch.  One GPU: 8.  N > 1: the frames of one gather (one collective per G frames: the call costs the root's
     # host 13+ us, a third of the time a 1/8 share of this frame takes; and a launch over one share of ONE frame is bounded by its
     # slowest pixel, not by throughput).
     if world > 1:
@@ -273,7 +270,9 @@ def main():
     else:
         # 8 frames per launch (a 20-step run: 8 + 8 + 4, measured equal to five launches of 4 — 0.240 ms per frame — with the
         # per-launch figures of the steady state); 4 only for runs shorter than two such launches
-        B = args.batch if args.batch > 0 else (2 if scene_mb > 256 else 8 if args.steps >= 16 else 4)
+        # (round 2 used 2 frames per launch for scenes beyond the 256 MB Infinity Cache; re-measured in round 3 the 10 M soup too is fastest
+        # with 8: 3.683 / 3.638 / 3.623 / 3.616 ms per frame with 2 / 4 / 6 / 8)
+        B = args.batch if args.batch > 0 else (8 if args.steps >= 16 else 4)
     B = max(1, min(16, B))
     if args.variant != 0:
         B = 1
