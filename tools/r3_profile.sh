@@ -9,9 +9,9 @@ cp gpurun_out/prof_${tag}_atrium/summary.txt gpurun_out/${tag}_atrium_summary.tx
 python3 tools/make_counters.py gpurun_out/${tag}_atrium_summary.txt atrium_1080p 8 valu_issue profiles/${tag}_atrium_summary.txt || exit 1
 cp profiles/counters_atrium_1080p.json gpurun_out/
 find gpurun_out/prof_${tag}_atrium/trace -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_atrium_kernel_stats.csv \;
-PMC_STEPS=4 PMC_WARMUP=2 tools/profile_gpu.sh ${tag}_soup10m --workload soup_10m_4k --streams 1 --batch 2 --steps 40 --warmup 10 > gpurun_out/${tag}_soup10m_profile.log 2>&1 || { echo "soup profile failed"; tail -5 gpurun_out/${tag}_soup10m_profile.log; exit 1; }
+PMC_STEPS=4 PMC_WARMUP=2 tools/profile_gpu.sh ${tag}_soup10m --workload soup_10m_4k --streams 1 --batch 8 --steps 40 --warmup 8 > gpurun_out/${tag}_soup10m_profile.log 2>&1 || { echo "soup profile failed"; tail -5 gpurun_out/${tag}_soup10m_profile.log; exit 1; }
 cp gpurun_out/prof_${tag}_soup10m/summary.txt gpurun_out/${tag}_soup10m_summary.txt
-python3 tools/make_counters.py gpurun_out/${tag}_soup10m_summary.txt soup_10m_4k 2 tcp_access_rate profiles/${tag}_soup10m_summary.txt || exit 1
+python3 tools/make_counters.py gpurun_out/${tag}_soup10m_summary.txt soup_10m_4k 8 tcp_access_rate profiles/${tag}_soup10m_summary.txt || exit 1
 cp profiles/counters_soup_10m_4k.json gpurun_out/
 find gpurun_out/prof_${tag}_soup10m/trace -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_soup10m_kernel_stats.csv \;
 rm -rf gpurun_out/prof_${tag}_atrium/pmc_* gpurun_out/prof_${tag}_soup10m/pmc_* gpurun_out/prof_${tag}_atrium/trace gpurun_out/prof_${tag}_soup10m/trace
